@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the FA-2 forward hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--variant auto] [--gather]
+
+One "step" = one forward pass of the hot path (flash_attention_forward -> C ABI -> HIP kernel) over one
+batch of synthetic input that is already resident in HBM.  The workload is BASELINE.json's metric
+config c3: B=4 H=32 N=4096 d=128 bf16, causal, scale=1 (the reference's math, src/bench.py:85), inputs
+N(0,1) drawn with seed 42 (src/bench.py:26,64-66).  FLOPs follow the convention the reference vendors
+(src/flash_attention_openai_tutorial.py:630-633): 4*B*H*N^2*d, halved for causal.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL): the path shards over
+(batch, head) with NO data-path collective -- every rank runs the c3 workload as its own head shard of a
+G-times-wider problem (weak scaling); value = total FLOPs of all ranks / max-over-ranks time.  The
+optional exchange step of the north star, an RCCL all-gather of the output shards over xGMI, is timed
+separately after the main region and reported under "gather" (use --gather to put it inside the step).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {  # BASELINE.json "configs"
+    "c2": dict(B=2, H=8, N=1024, d=64, dtype="fp16", causal=False),
+    "c3": dict(B=4, H=32, N=4096, d=128, dtype="bf16", causal=True),
+    "c3_noncausal": dict(B=4, H=32, N=4096, d=128, dtype="bf16", causal=False),
+    "c4_per_gpu": dict(B=8, H=8, N=8192, d=128, dtype="bf16", causal=False),
+    "ref_test": dict(B=32, H=32, N=256, d=128, dtype="f32", causal=False),  # src/test_correctness.py:9-14
+}
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
+# Dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (TFLOP/s)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}
+
+
+def flops(c):
+    f = 4.0 * c["B"] * c["H"] * c["N"] ** 2 * c["d"]
+    return f * 0.5 if c["causal"] else f
+
+
+def cpu_baseline(c, budget_s=12.0):
+    """The reference's CPU path -- torch SDPA(scale=1) on fp32 CPU tensors (src/test_correctness.py:33) --
+    on a bounded sample of the same workload: same N, d, causal; B=1 and a few heads."""
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    Hs = min(4, c["H"])
+    sc = dict(c, B=1, H=Hs)
+    g = torch.Generator().manual_seed(42)
+    Q, K, V = (torch.randn(1, Hs, c["N"], c["d"], generator=g) for _ in range(3))
+    fn = lambda: torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1.0, is_causal=c["causal"])
+    fn()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        fn()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 50:
+            break
+    gf = flops(sc) * reps / el / 1e9
+    out = {"value": round(gf / 1e3, 5), "unit": "TFLOP/s", "cores": ncores, "kind": "reference",
+           "sample": f"torch SDPA(scale=1) fp32 on CPU, B=1 H={Hs} N={c['N']} d={c['d']} causal={c['causal']}, "
+                     f"{reps} reps in {el:.1f}s", "gflops": round(gf, 2)}
+    # the oracle's scalar C port, one core, on a smaller slice (N^2 work: keep it to a few seconds)
+    try:
+        from oracle import fa2_oracle
+        n = min(c["N"], 1024)
+        q, k, v = (x[:, :1, :n].contiguous().numpy() for x in (Q, K, V))
+        t1 = time.perf_counter()
+        fa2_oracle.forward(q, k, v, "float32", causal=c["causal"], B_r=64, B_c=64)
+        el1 = time.perf_counter() - t1
+        f1 = 4.0 * n * n * c["d"] * (0.5 if c["causal"] else 1.0)
+        out["port_1core_gflops"] = round(f1 / el1 / 1e9, 3)
+        out["port_sample"] = f"oracle/fa2_oracle.c, 1 core, B=1 H=1 N={n} d={c['d']}"
+    except Exception as e:  # the baseline leg must never take the bench down
+        out["port_error"] = str(e)[:100]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--variant", default="auto")
+    ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of O in the timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the scaled-input and gather side measurements")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from flash_attention_dlrs_amd import _lib, flash_attention_forward
+    from flash_attention_dlrs_amd.sharded import flash_attention_forward_sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    c = CONFIGS[args.config]
+    dtype = TORCH_DTYPE[c["dtype"]]
+    torch.manual_seed(42 + rank)  # src/bench.py:26; rank r draws its own head shard
+    Q, K, V = (torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev).to(dtype) for _ in range(3))
+    variant = args.variant
+
+    def step():
+        if args.gather and world > 1:
+            return flash_attention_forward_sharded(Q, K, V, causal=c["causal"], gather=True)
+        return flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant=variant)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for s, e in ev:  # HIP events on the stream the kernel is launched on (torch's current stream)
+        s.record()
+        step()
+        e.record()
+    sync_all()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
+    kern_avg = sum(kern_ms) / len(kern_ms)
+
+    F = flops(c)
+    ms_per_step = el * 1e3 / args.steps
+    value = world * F / (el / args.steps) / 1e12
+    peak = PEAK_TFLOPS[c["dtype"]]
+    achieved = F / (kern_avg * 1e-3) / 1e12
+    tile = _lib.query_tile(c["N"], c["d"], {"bf16": 2, "fp16": 1, "f32": 0}[c["dtype"]], c["causal"])
+
+    extras = {}
+    if not args.no_extras:
+        # (1) inputs scaled by d^-1/4 (== the usual 1/sqrt(d)): softmax no longer nearly one-hot
+        s4 = c["d"] ** -0.25
+        Q2, K2 = (Q.float() * s4).to(dtype), (K.float() * s4).to(dtype)
+        for _ in range(3):
+            flash_attention_forward(Q2, K2, V, dev, causal=c["causal"], variant=variant)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        a.record()
+        for _ in range(10):
+            flash_attention_forward(Q2, K2, V, dev, causal=c["causal"], variant=variant)
+        b.record()
+        torch.cuda.synchronize(dev)
+        extras["tflops_inputs_scaled_d^-1/4"] = round(F / (a.elapsed_time(b) / 10 * 1e-3) / 1e12, 2)
+        del Q2, K2
+        # (2) the optional exchange step: all-gather of the O shards over xGMI, overlapped per batch element
+        if world > 1:
+            for _ in range(2):
+                flash_attention_forward_sharded(Q, K, V, causal=c["causal"], gather=True)
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                flash_attention_forward_sharded(Q, K, V, causal=c["causal"], gather=True)
+            sync_all()
+            tg = (time.perf_counter() - t1) / 5
+            o_bytes = Q.numel() * Q.element_size()
+            extras["gather"] = {"included_in_step": bool(args.gather), "ms_compute_plus_gather": round(tg * 1e3, 4),
+                                "o_shard_MiB": o_bytes / 2 ** 20,
+                                "tflops_with_gather": round(world * F / tg / 1e12, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(c)
+
+    if rank == 0:
+        out = {
+            "metric": "attention fwd TFLOP/s per GPU (B=4,H=32,N=4096,d=128 bf16); % MFMA peak",
+            "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": c["dtype"], "data": "synthetic",
+            "config": {"workload": f"{args.config}: FA-2 forward B={c['B']} H={c['H']} N={c['N']} d={c['d']} "
+                                   f"{c['dtype']} causal={c['causal']} scale=1 per GPU; seed 42+rank N(0,1)",
+                       "kernel_variant": variant, "tile": {"variant": tile[0], "B_r": tile[1], "B_c": tile[2],
+                                                           "waves": tile[3]},
+                       "sharding": "heads" if world > 1 else "none",
+                       "flops_per_step_per_gpu": F, "pct_of_mfma_peak": round(100 * value / world / peak, 2)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel_ms_avg": round(kern_avg, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
+                         "kernel_ms_min": round(kern_ms[0], 5)},
+            "cpu_baseline": cpu,
+            "extras": extras,
+            "lib": _lib.version(),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

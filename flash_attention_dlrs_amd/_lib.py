@@ -1,0 +1,93 @@
+"""ctypes binding of libfa2_hip.so -- the only way the Python surface reaches the GPU.
+
+Replaces the `fwd_kernel[grid](...)` Triton launch of the reference
+(src/flash_attention_torch.py:59-74, src/flash_attention_wrappers.py:46-61).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfa2_hip.so")
+
+FA2_DTYPE_F32, FA2_DTYPE_F16, FA2_DTYPE_BF16, FA2_DTYPE_F8E5M2, FA2_DTYPE_F8E4M3, FA2_DTYPE_F64 = range(6)
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA16, VARIANT_MFMA16_W8, VARIANT_MFMA32 = range(5)
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_MFMA16,
+            "mfma16_w8": VARIANT_MFMA16_W8, "mfma32": VARIANT_MFMA32}
+
+# Every symbol include/fa2_fwd.h declares (tests/test_abi.py checks the export list against the header).
+SYMBOLS = ("fa2_fwd", "fa2_fwd_variant", "fa2_query_tile", "fa2_version", "fa2_last_error")
+
+_lib = None
+
+
+class Fa2LibraryMissing(ImportError):
+    pass
+
+
+def lib():
+    """Load the C-ABI library.  No fallback: a missing build is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Fa2LibraryMissing(
+                f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C flash_attention_dlrs_amd/csrc`. There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        vp = ctypes.c_void_p
+        common = [vp, vp, vp, vp, vp, i64p, i64p, i64p, i64p, i64p] + [ctypes.c_int32] * 6 + [ctypes.c_float, vp]
+        l.fa2_fwd.restype = ctypes.c_int
+        l.fa2_fwd.argtypes = common
+        l.fa2_fwd_variant.restype = ctypes.c_int
+        l.fa2_fwd_variant.argtypes = common + [ctypes.c_int32]
+        l.fa2_query_tile.restype = ctypes.c_int
+        l.fa2_query_tile.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
+        l.fa2_version.restype = ctypes.c_char_p
+        l.fa2_last_error.restype = ctypes.c_char_p
+        _lib = l
+    return _lib
+
+
+def version():
+    return lib().fa2_version().decode()
+
+
+def query_tile(N, d, dtype_enum, causal=False):
+    out = (ctypes.c_int32 * 4)()
+    rc = lib().fa2_query_tile(N, d, dtype_enum, int(bool(causal)), out)
+    if rc != 0:
+        _raise(rc)
+    return tuple(out)
+
+
+def _raise(rc):
+    msg = lib().fa2_last_error().decode()
+    if rc == -2:
+        raise TypeError(f"fa2_fwd: {msg}")           # reference: TypeError for unsupported dtype (torch.py:18)
+    if rc in (-1, -3):
+        raise ValueError(f"fa2_fwd: {msg}")          # reference: ValueError for bad shapes (torch.py:28-32)
+    raise RuntimeError(f"fa2_fwd rc={rc}: {msg}")
+
+
+def _i64(vals):
+    return (ctypes.c_int64 * len(vals))(*vals)
+
+
+def fa2_fwd(Q, K, V, O, L, dtype_enum, causal=False, scale=1.0, variant=VARIANT_AUTO):
+    """Launch the forward on the current stream of Q's device.  Tensors are (B, H, N, d) with
+    arbitrary strides; O (B, H, N, d) and L (B, H, N, 1) are pre-allocated by the caller exactly as
+    the reference's host glue does (torch.py:50-51)."""
+    if Q.device.type != "cuda":
+        raise NotImplementedError("Q, K, V must be on the same CUDA device")
+    B, H, N, d = Q.shape
+    LB, LH = L.stride(0), L.stride(1)
+    with torch.cuda.device(Q.device):
+        stream = torch.cuda.current_stream(Q.device).cuda_stream
+        rc = lib().fa2_fwd_variant(
+            Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
+            _i64(Q.stride()), _i64(K.stride()), _i64(V.stride()), _i64(O.stride()), _i64((LB, LH)),
+            B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), stream, int(variant))
+    if rc != 0:
+        _raise(rc)

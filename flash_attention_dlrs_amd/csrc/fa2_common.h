@@ -1,0 +1,41 @@
+// Shared declarations of the gfx950 FA-2 forward kernels (internal; the public ABI is include/fa2_fwd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fa2_fwd.h"
+
+// One forward problem, as handed over by fa2_fwd().  Strides in elements (reference convention,
+// src/flash_attention_torch.py:53-57).
+struct Fa2Problem {
+    const void *Q, *K, *V;
+    void *O, *L;
+    int64_t qs[4], ks[4], vs[4], os[4], ls[2];
+    int32_t B, H, N, d;
+    int32_t dtype, causal;
+    float scale;
+    hipStream_t stream;
+};
+
+// Launchers, one per translation unit.  Return FA2_OK / FA2_ERR_*; set_error() on failure.
+int fa2_launch_generic(const Fa2Problem &p);
+int fa2_launch_mfma16(const Fa2Problem &p, int waves);
+int fa2_launch_mfma32(const Fa2Problem &p);
+bool fa2_mfma16_supports(const Fa2Problem &p);
+bool fa2_mfma32_supports(const Fa2Problem &p);
+
+void fa2_set_error(const char *fmt, ...);
+
+static inline int fa2_dtype_size(int dt) {
+    switch (dt) {
+    case FA2_DTYPE_F64: return 8;
+    case FA2_DTYPE_F32: return 4;
+    case FA2_DTYPE_F16:
+    case FA2_DTYPE_BF16: return 2;
+    case FA2_DTYPE_F8E5M2:
+    case FA2_DTYPE_F8E4M3: return 1;
+    default: return 0;
+    }
+}
+
+#define FA2_LOG2E 1.4426950408889634  // np.log2(np.e), src/flash_attention_kernels.py:9

@@ -1,0 +1,151 @@
+"""torch surface of the FA-2 forward -- counterpart of the reference's src/flash_attention_torch.py.
+
+Same names, arity, checks, exceptions, padding and return values as the reference:
+  MIN_TENSOR_SIZE, convert_triton_dtype           (reference torch.py:5-18)
+  FlashAttention, FlashAttentionDeterministic      (reference torch.py:21-158, :161-294)
+The forward launches the hand-written gfx950 kernel through the C ABI (include/fa2_fwd.h) instead
+of Triton.  `causal` and `scale` are optional extra positional arguments of `.apply` with
+reference-preserving defaults (no mask, scale 1).
+
+The backward is OUT OF the hot-path scope: it is provided so that
+`.backward()` works, as a device-side torch recompute from the saved log-sum-exp L -- not a native
+kernel (the reference's own backward kernels are documented as unreliable, README.md:45-53).
+"""
+import math
+
+import torch
+
+from . import _lib
+
+MIN_TENSOR_SIZE = 16
+
+_DTYPE_MAP = {
+    torch.float64: _lib.FA2_DTYPE_F64,
+    torch.float32: _lib.FA2_DTYPE_F32,
+    torch.float16: _lib.FA2_DTYPE_F16,
+    torch.float8_e5m2: _lib.FA2_DTYPE_F8E5M2,
+    # extensions (BASELINE.json configs c3-c5); the reference raises TypeError for these
+    torch.bfloat16: _lib.FA2_DTYPE_BF16,
+    torch.float8_e4m3fn: _lib.FA2_DTYPE_F8E4M3,
+}
+
+
+def convert_triton_dtype(torch_dtype):
+    """torch dtype -> kernel dtype enum (include/fa2_fwd.h FA2_DTYPE_*).  Name kept from the
+    reference (torch.py:7-18), where it returns a triton dtype; TypeError for anything unsupported."""
+    try:
+        return _DTYPE_MAP[torch_dtype]
+    except KeyError:
+        raise TypeError(f"dtype {torch_dtype} not supported.") from None
+
+
+def next_power_of_2(n):
+    return 1 << (int(n) - 1).bit_length() if n > 1 else 1
+
+
+def pad_last_dim(t, d_proper):
+    """Zero-pad the last dimension to d_proper (reference torch.py:40-45).  fp8 tensors are padded
+    through their byte view (0x00 is +0.0 in both fp8 formats)."""
+    d = t.shape[-1]
+    if d == d_proper:
+        return t
+    if t.dtype in (torch.float8_e5m2, torch.float8_e4m3fn):
+        out = torch.zeros(*t.shape[:-1], d_proper, dtype=torch.uint8, device=t.device)
+        out[..., :d] = t.view(torch.uint8)
+        return out.view(t.dtype)
+    return torch.nn.functional.pad(t, (0, d_proper - d), mode="constant", value=0.0)
+
+
+def _check_inputs(Q, K, V):
+    dev = Q.device
+    if dev.type != "cuda" or dev != K.device or dev != V.device:
+        raise NotImplementedError("Q, K, V must be on the same CUDA device")
+    if Q.dim() != 4 or Q.shape != K.shape or Q.shape != V.shape:
+        raise ValueError("Q, K, V must all be of shape (B, H, N, d)")
+    if Q.dtype != K.dtype or K.dtype != V.dtype:
+        raise ValueError("Q, K, V must have same dtype")
+
+
+def _forward_impl(ctx, Q, K, V, causal, scale):
+    _check_inputs(Q, K, V)
+    B, H, N, d = Q.shape
+    dtype = convert_triton_dtype(Q.dtype)
+
+    # Support for non-power-of-2 d or d < 16 (reference torch.py:38)
+    d_proper = max(next_power_of_2(d), MIN_TENSOR_SIZE)
+    padded = d_proper != d
+    if padded:
+        Q, K, V = (pad_last_dim(t, d_proper) for t in (Q, K, V))
+
+    # O inherits Q's strides, L is (B, H, N, 1) in the input dtype (reference torch.py:50-51)
+    O = torch.empty_like(Q)
+    L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=Q.device)
+
+    _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale)
+
+    ctx.save_for_backward(Q, K, V, O, L)
+    ctx.padded = padded
+    ctx.d_used = d_proper
+    ctx.d_orig = d
+    ctx.causal = bool(causal)
+    ctx.scale = float(scale)
+    return O[:, :, :, 0:d] if padded else O
+
+
+def attention_backward_recompute(Q, K, V, O, dO, L, causal=False, scale=1.0):
+    """dQ, dK, dV from the saved statistics, in torch ops on the tensors' device (NOT a native kernel).
+    P = exp2(scale * S * log2e - L) (reference kernels.py:283-285), D = rowsum(dO * O) (kernels.py:120-166)."""
+    f = torch.float64 if Q.dtype == torch.float64 else torch.float32
+    q, k, v, o, do, l = (t.to(f) for t in (Q, K, V, O, dO, L))
+    S = torch.matmul(q, k.transpose(-1, -2)) * (scale * math.log2(math.e))
+    if causal:
+        N = Q.shape[2]
+        mask = torch.ones(N, N, dtype=torch.bool, device=Q.device).tril()
+        S = S.masked_fill(~mask, float("-inf"))
+    P = torch.exp2(S - l)
+    dV = torch.matmul(P.transpose(-1, -2), do)
+    dP = torch.matmul(do, v.transpose(-1, -2))
+    D = (do * o).sum(dim=-1, keepdim=True)
+    dS = P * (dP - D) * scale
+    dQ = torch.matmul(dS, k)
+    dK = torch.matmul(dS.transpose(-1, -2), q)
+    return dQ.to(Q.dtype), dK.to(K.dtype), dV.to(V.dtype)
+
+
+def _backward_impl(ctx, dO):
+    Q, K, V, O, L = ctx.saved_tensors
+    if Q.dtype != dO.dtype:
+        raise ValueError("dO must have same dtype as inputs")
+    if ctx.padded:
+        dO = pad_last_dim(dO, ctx.d_used)
+    dQ, dK, dV = attention_backward_recompute(Q, K, V, O, dO, L, ctx.causal, ctx.scale)
+    if ctx.padded:
+        d = ctx.d_orig
+        return dQ[..., :d], dK[..., :d], dV[..., :d], None, None
+    return dQ, dK, dV, None, None
+
+
+class FlashAttention(torch.autograd.Function):
+    """O = softmax(Q K^T) V with scale 1 (reference torch.py:21-84).  `FlashAttention.apply(Q, K, V)`;
+    optional extras `FlashAttention.apply(Q, K, V, causal, scale)`."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, causal=False, scale=1.0):
+        return _forward_impl(ctx, Q, K, V, causal, scale)
+
+    @staticmethod
+    def backward(ctx, grad_outputs, *args):
+        return _backward_impl(ctx, grad_outputs)
+
+
+class FlashAttentionDeterministic(torch.autograd.Function):
+    """Same forward as FlashAttention (the reference's two forwards are identical, torch.py:161-224);
+    the recompute backward used here is deterministic by construction."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, causal=False, scale=1.0):
+        return _forward_impl(ctx, Q, K, V, causal, scale)
+
+    @staticmethod
+    def backward(ctx, grad_outputs, *args):
+        return _backward_impl(ctx, grad_outputs)

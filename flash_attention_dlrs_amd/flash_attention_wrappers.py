@@ -1,0 +1,43 @@
+"""Plain-function surface -- counterpart of the reference's src/flash_attention_wrappers.py.
+
+flash_attention_forward(Q, K, V, dev) -> (O, L) is the entry point of the reference's correctness
+script (src/test_correctness.py:34) and the only place the log2-domain log-sum-exp L is exposed.
+"""
+import torch
+
+from . import _lib
+from .flash_attention_torch import (MIN_TENSOR_SIZE, attention_backward_recompute, convert_triton_dtype,
+                                    next_power_of_2, pad_last_dim)
+
+
+def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="auto"):
+    # Takes tensors of shape (B, H, N, d): batch, heads, context size, head dimension
+    # (reference wrappers.py:14-22: bare asserts, kept).
+    assert Q.dim() == 4
+    assert Q.shape == K.shape and K.shape == V.shape
+    assert Q.dtype == K.dtype and K.dtype == V.dtype
+
+    B, H, N, d = Q.shape
+
+    # The reference pads to next_pow2(d) only (wrappers.py:27) and then breaks Triton's 16-minimum
+    # for d < 16; both of our surfaces pad to max(next_pow2(d), 16) like torch.py:38.
+    d_pow = max(next_power_of_2(d), MIN_TENSOR_SIZE)
+    if d_pow != d:
+        Q, K, V = (pad_last_dim(t, d_pow) for t in (Q, K, V))
+
+    # Always-contiguous outputs (reference wrappers.py:37-38)
+    O = torch.empty(B, H, N, d_pow, dtype=Q.dtype, device=dev)
+    L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=dev)
+
+    _lib.fa2_fwd(Q, K, V, O, L, convert_triton_dtype(Q.dtype), causal=causal, scale=scale,
+                 variant=_lib.VARIANTS[variant])
+
+    return O[:, :, :, 0:d], L
+
+
+def flash_attention_backward(Q, K, V, O, dO, L, dev, deterministic=False, *, causal=False, scale=1.0):
+    """(dQ, dK, dV).  Out of the hot-path scope: a torch recompute on
+    `dev`, not a native kernel; `deterministic` is accepted for signature parity (wrappers.py:66-75)."""
+    assert Q.dim() == 4
+    assert Q.shape == K.shape and K.shape == V.shape and O.shape == Q.shape and dO.shape == Q.shape
+    return attention_backward_recompute(Q, K, V, O, dO, L, causal=causal, scale=scale)

@@ -1,0 +1,92 @@
+/*
+ * fa2_fwd.h -- C ABI of the MI355X-native Flash-Attention-2 forward (libfa2_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of 17ex/flash_attention_dlrs: the Triton launch
+ *
+ *     fwd_kernel[grid](Q, K, V, O, L,
+ *                      QB,QH,QN,Qd, KB,KH,KN,Kd, VB,VH,VN,Vd, OB,OH,ON,Od, LB,LH,
+ *                      B, H, N, d, dtype)
+ *
+ * made at  src/flash_attention_torch.py:61-74, :201-214  and  src/flash_attention_wrappers.py:48-61
+ * of the kernel defined at  src/flash_attention_kernels.py:17-109.  fa2_fwd() takes the same
+ * argument list (pointers instead of torch tensors, strides in ELEMENTS exactly as the reference
+ * passes them) plus the three reference-preserving extensions BASELINE.json asks for (causal,
+ * scale, stream).  No torch types, no C++ types, no exceptions cross this boundary.
+ *
+ * Ownership: the caller owns every buffer.  O and L are allocated by the caller BEFORE the call
+ * (flash_attention_torch.py:50-51); the library only writes into them, allocates nothing, and keeps
+ * no pointer after returning.  The launch is asynchronous on `hip_stream`.
+ * Threading: re-entrant; the only mutable state is the thread-local last-error string.
+ */
+#ifndef FA2_FWD_H
+#define FA2_FWD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dtype_enum.  Replaces convert_triton_dtype (src/flash_attention_torch.py:7-18), which maps
+ * float64 / float32 / float16 / float8_e5m2.  bf16 and OCP e4m3fn are extensions. */
+#define FA2_DTYPE_F32 0
+#define FA2_DTYPE_F16 1
+#define FA2_DTYPE_BF16 2
+#define FA2_DTYPE_F8E5M2 3
+#define FA2_DTYPE_F8E4M3 4
+#define FA2_DTYPE_F64 5
+
+/* Return codes (the Python glue re-raises them as the exception classes the reference uses,
+ * flash_attention_torch.py:24-32, :18). */
+#define FA2_OK 0
+#define FA2_ERR_BAD_ARG (-1)     /* null pointer, non-positive size, misaligned/negative stride  */
+#define FA2_ERR_UNSUPPORTED (-2) /* dtype enum unknown, or d not a power of two in [16, 512]     */
+#define FA2_ERR_BAD_N (-3)       /* N < 1                                                        */
+#define FA2_ERR_LAUNCH (-4)      /* HIP reported an error at launch                              */
+
+/* Kernel variants (fa2_fwd_variant / fa2_query_tile).  AUTO = the static gfx950 tile table that
+ * replaces the reference's run-time autotuner (src/autotune_configs.py:24-201, kernels.py:11-15). */
+#define FA2_VARIANT_AUTO 0
+#define FA2_VARIANT_GENERIC 1 /* any dtype, any strides, d = 2^k in [16,512], any N; FMA on VALU  */
+#define FA2_VARIANT_MFMA16 2  /* f16/bf16, d in {64,128}, unit d-stride; 4 waves x 32 rows         */
+#define FA2_VARIANT_MFMA16_W8 3 /* same, 8 waves x 32 rows (256-row Q tile)                        */
+#define FA2_VARIANT_MFMA32 4  /* f32 via v_mfma_f32_32x32x2_f32, d in {64,128}                     */
+
+/*
+ * O = softmax(scale * Q K^T [+ causal mask]) V   and   L = log2-domain log-sum-exp of the scores,
+ * L = m + log2(l)  (src/flash_attention_kernels.py:105-108).  scale = 1, causal = 0 is the reference.
+ *
+ *   Q, K, V : device pointers, logical shape (B, H, N, d), element strides q/k/v_strides[4]
+ *   O       : device pointer, (B, H, N, d), strides o_strides[4], written in dtype_enum
+ *   L       : device pointer, (B, H, N, 1) in dtype_enum; l_strides = {LB, LH}; unit stride over N
+ *             (kernels.py:59-65)
+ *   hip_stream : hipStream_t (may be NULL = default stream)
+ */
+int fa2_fwd(const void *Q, const void *K, const void *V, void *O, void *L,
+            const int64_t q_strides[4], const int64_t k_strides[4], const int64_t v_strides[4],
+            const int64_t o_strides[4], const int64_t l_strides[2], int32_t B, int32_t H, int32_t N,
+            int32_t d, int32_t dtype_enum, int32_t causal, float scale, void *hip_stream);
+
+/* Same, forcing one kernel variant (tests and bench A/B).  FA2_ERR_UNSUPPORTED if the variant
+ * cannot run the given problem. */
+int fa2_fwd_variant(const void *Q, const void *K, const void *V, void *O, void *L,
+                    const int64_t q_strides[4], const int64_t k_strides[4],
+                    const int64_t v_strides[4], const int64_t o_strides[4],
+                    const int64_t l_strides[2], int32_t B, int32_t H, int32_t N, int32_t d,
+                    int32_t dtype_enum, int32_t causal, float scale, void *hip_stream,
+                    int32_t variant);
+
+/* Which tile the static table picks for a contiguous problem: out4 = {variant, B_r, B_c, waves}.
+ * Counterpart of fwd_conf_prune + the autotuner's choice (src/autotune_configs.py:176-194). */
+int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int32_t out4[4]);
+
+/* "fa2-hip <semver> gfx950". */
+const char *fa2_version(void);
+
+/* Message of the last non-zero return on the calling thread ("" if none). */
+const char *fa2_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA2_FWD_H */

@@ -1,0 +1,102 @@
+"""The C-ABI library loads and exports every symbol include/fa2_fwd.h declares; argument validation
+(which happens before any HIP call) returns the documented codes.  No compute, no GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+from flash_attention_dlrs_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "fa2_fwd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fa2_\w+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    l = _lib.lib()
+    for name in declared_functions():
+        assert getattr(l, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared_functions():
+        assert re.search(rf"\bT {name}\b", out), name
+
+
+def test_exported_fa2_symbols_are_only_the_c_abi():
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (fa2_\w+)\b", out))
+    assert exported == set(declared_functions())
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    c = tmp_path / "t.c"
+    c.write_text('#include "fa2_fwd.h"\nint main(void){return FA2_OK + (fa2_version()!=0);}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                           str(c), "-o", str(tmp_path / "t.o")])
+
+
+def test_version_string():
+    assert _lib.version().startswith("fa2-hip ") and "gfx950" in _lib.version()
+
+
+def _call(N=64, d=64, dtype=_lib.FA2_DTYPE_F32, ptr=0x1000, B=1, H=1, strides=None, scale=1.0):
+    s = strides or (H * N * d, N * d, d, 1)
+    i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
+    return _lib.lib().fa2_fwd(ptr, ptr, ptr, ptr, ptr, i64(s), i64(s), i64(s), i64(s), i64((H * N, N)),
+                              B, H, N, d, dtype, 0, scale, None)
+
+
+@pytest.mark.parametrize("kwargs,code,needle", [
+    (dict(ptr=0), -1, "null"),
+    (dict(B=0), -1, "positive"),
+    (dict(N=0), -3, "N must be"),
+    (dict(d=48), -2, "power of two"),
+    (dict(d=8), -2, "power of two"),
+    (dict(d=1024), -2, "power of two"),
+    (dict(dtype=99), -2, "dtype"),
+    (dict(strides=(-1, 1, 1, 1)), -1, "negative"),
+    (dict(scale=float("nan")), -1, "NaN"),
+])
+def test_validation_codes_before_any_launch(kwargs, code, needle):
+    assert _call(**kwargs) == code
+    assert needle in _lib.lib().fa2_last_error().decode()
+
+
+def test_exception_mapping_mirrors_reference():
+    # reference: TypeError for an unsupported dtype (torch.py:18), ValueError for bad shapes (torch.py:28-32)
+    _call(dtype=99)
+    with pytest.raises(TypeError):
+        _lib._raise(-2)
+    with pytest.raises(ValueError):
+        _lib._raise(-1)
+    with pytest.raises(ValueError):
+        _lib._raise(-3)
+    with pytest.raises(RuntimeError):
+        _lib._raise(-4)
+
+
+def test_static_tile_table():
+    q = _lib.query_tile
+    # north-star config c3 and friends take the MFMA paths; odd head sizes and exotic dtypes fall back
+    assert q(4096, 128, _lib.FA2_DTYPE_BF16, True)[0] in (_lib.VARIANT_MFMA16, _lib.VARIANT_MFMA16_W8)
+    assert q(1024, 64, _lib.FA2_DTYPE_F16)[0] in (_lib.VARIANT_MFMA16, _lib.VARIANT_MFMA16_W8)
+    assert q(256, 128, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32
+    assert q(128, 32, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_GENERIC
+    assert q(128, 64, _lib.FA2_DTYPE_F64)[0] == _lib.VARIANT_GENERIC
+    assert q(128, 128, _lib.FA2_DTYPE_F8E5M2)[0] == _lib.VARIANT_GENERIC
+    # supported N domain is a superset of the reference's (multiples of 16, autotune_configs.py:176-187)
+    for N in (16, 48, 100, 4096):
+        assert q(N, 64, _lib.FA2_DTYPE_F32)[1] > 0
+    with pytest.raises(TypeError):
+        q(128, 24, _lib.FA2_DTYPE_F32)

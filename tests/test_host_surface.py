@@ -1,0 +1,91 @@
+"""Host-side mirror of the reference's Python surface (src/flash_attention_torch.py,
+src/flash_attention_wrappers.py): names, checks, exceptions, padding helpers.  CPU only."""
+import math
+
+import pytest
+import torch
+
+import flash_attention_dlrs_amd as fa
+from flash_attention_dlrs_amd import _lib, flash_attention_torch as ft
+
+
+def test_public_names_match_reference_modules():
+    for name in ("FlashAttention", "FlashAttentionDeterministic", "convert_triton_dtype", "MIN_TENSOR_SIZE",
+                 "flash_attention_forward", "flash_attention_backward"):
+        assert hasattr(fa, name)
+    assert fa.MIN_TENSOR_SIZE == 16  # reference torch.py:5
+    assert issubclass(fa.FlashAttention, torch.autograd.Function)
+    assert issubclass(fa.FlashAttentionDeterministic, torch.autograd.Function)
+
+
+def test_convert_dtype_map_and_typeerror():
+    # reference torch.py:7-18 maps exactly these four ...
+    assert fa.convert_triton_dtype(torch.float64) == _lib.FA2_DTYPE_F64
+    assert fa.convert_triton_dtype(torch.float32) == _lib.FA2_DTYPE_F32
+    assert fa.convert_triton_dtype(torch.float16) == _lib.FA2_DTYPE_F16
+    assert fa.convert_triton_dtype(torch.float8_e5m2) == _lib.FA2_DTYPE_F8E5M2
+    # ... we add bf16 and e4m3fn (BASELINE.json c3-c5) ...
+    assert fa.convert_triton_dtype(torch.bfloat16) == _lib.FA2_DTYPE_BF16
+    assert fa.convert_triton_dtype(torch.float8_e4m3fn) == _lib.FA2_DTYPE_F8E4M3
+    # ... and everything else raises TypeError like the reference
+    for bad in (torch.int32, torch.int8, torch.bool, torch.complex64):
+        with pytest.raises(TypeError):
+            fa.convert_triton_dtype(bad)
+
+
+def test_cpu_tensors_are_refused_like_the_reference():
+    x = torch.zeros(1, 1, 16, 16)
+    for fn in (fa.FlashAttention.apply, fa.FlashAttentionDeterministic.apply):
+        with pytest.raises(NotImplementedError, match="same CUDA device"):  # reference torch.py:25-26
+            fn(x, x, x)
+    with pytest.raises((NotImplementedError, RuntimeError, AssertionError)):
+        fa.flash_attention_forward(x, x, x, torch.device("cpu"))
+
+
+def test_wrapper_asserts_like_the_reference():
+    a, b = torch.zeros(1, 1, 16, 16), torch.zeros(1, 1, 32, 16)
+    with pytest.raises(AssertionError):  # reference wrappers.py:20-22
+        fa.flash_attention_forward(a, b, a, torch.device("cpu"))
+    with pytest.raises(AssertionError):
+        fa.flash_attention_forward(a[0], a[0], a[0], torch.device("cpu"))
+    with pytest.raises(AssertionError):
+        fa.flash_attention_forward(a, a.half(), a, torch.device("cpu"))
+
+
+def test_padding_helpers():
+    assert [ft.next_power_of_2(n) for n in (1, 2, 3, 8, 9, 40, 64, 65, 128)] == [1, 2, 4, 8, 16, 64, 64, 128, 128]
+    t = torch.randn(2, 3, 5, 40)
+    p = ft.pad_last_dim(t, 64)
+    assert p.shape == (2, 3, 5, 64) and torch.equal(p[..., :40], t) and p[..., 40:].abs().max() == 0
+    assert ft.pad_last_dim(t, 40) is t
+    for dt in (torch.float8_e5m2, torch.float8_e4m3fn):
+        f8 = torch.randn(1, 1, 4, 8).to(dt)
+        p8 = ft.pad_last_dim(f8, 16)
+        assert p8.dtype == dt and torch.equal(p8[..., :8].view(torch.uint8), f8.view(torch.uint8))
+        assert p8[..., 8:].float().abs().max() == 0
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_recompute_backward_matches_autograd(causal):
+    """The (non-native, out-of-scope) backward: gradients from the saved log2-domain L equal autograd
+    through SDPA(scale=1)  -- the comparison src/test_correctness.py:46-62 makes."""
+    torch.manual_seed(0)
+    Q, K, V = (torch.randn(1, 2, 24, 8, dtype=torch.float64, requires_grad=True) for _ in range(3))
+    O = torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1.0, is_causal=causal)
+    dO = torch.randn_like(O)
+    gq, gk, gv = torch.autograd.grad(O, (Q, K, V), dO)
+    S = Q @ K.transpose(-1, -2)
+    if causal:
+        S = S.masked_fill(~torch.ones(24, 24, dtype=torch.bool).tril(), float("-inf"))
+    L = torch.logsumexp(S, dim=-1, keepdim=True) * math.log2(math.e)
+    dq, dk, dv = ft.attention_backward_recompute(Q.detach(), K.detach(), V.detach(), O.detach(), dO, L.detach(),
+                                                 causal=causal)
+    for a, b in ((dq, gq), (dk, gk), (dv, gv)):
+        assert torch.allclose(a, b, atol=1e-10)
+
+
+def test_library_missing_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback|not built"):
+        _lib.lib()
