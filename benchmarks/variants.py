@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""A/B harness: time several (config, kernel variant) pairs interleaved in ONE process
+(cdna_hip_programming.md rule 24) and print TFLOP/s per pair (median and best of the rounds).
+
+    python benchmarks/variants.py --pairs c3:mfma16_w8,c3:mfma16,c3_noncausal:mfma16_w8 --rounds 5 --iters 10
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import CONFIGS, PEAK_TFLOPS, TORCH_DTYPE, flops  # noqa: E402
+from flash_attention_dlrs_amd import flash_attention_forward  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", default="c3:mfma16_w8,c3:mfma16,c3_noncausal:mfma16_w8,c3_noncausal:mfma16")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    pairs = [p.split(":") for p in args.pairs.split(",")]
+    data = {}
+    for cfg, _ in pairs:
+        if cfg not in data:
+            c = CONFIGS[cfg]
+            torch.manual_seed(42)
+            data[cfg] = tuple(torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev).to(TORCH_DTYPE[c["dtype"]])
+                              for _ in range(3))
+    res = {f"{c}:{v}": [] for c, v in pairs}
+    for cfg, var in pairs:  # warm-up
+        Q, K, V = data[cfg]
+        for _ in range(3):
+            flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var)
+    torch.cuda.synchronize()
+    for _ in range(args.rounds):
+        for cfg, var in pairs:
+            Q, K, V = data[cfg]
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.iters):
+                flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var)
+            b.record()
+            torch.cuda.synchronize()
+            res[f"{cfg}:{var}"].append(a.elapsed_time(b) / args.iters)
+    for k, ms in res.items():
+        c = CONFIGS[k.split(":")[0]]
+        ms = sorted(ms)
+        med, best = ms[len(ms) // 2], ms[0]
+        tf = lambda t: flops(c) / (t * 1e-3) / 1e12
+        print(json.dumps({"pair": k, "ms_median": round(med, 4), "tflops_median": round(tf(med), 1),
+                          "tflops_best": round(tf(best), 1),
+                          "pct_peak_median": round(100 * tf(med) / PEAK_TFLOPS[c["dtype"]], 1)}))
+
+
+if __name__ == "__main__":
+    main()
