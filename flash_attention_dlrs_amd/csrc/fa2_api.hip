@@ -74,6 +74,8 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16: return fa2_launch_mfma16(p, 4);
     case FA2_VARIANT_MFMA16_W8: return fa2_launch_mfma16(p, 8);
     case FA2_VARIANT_MFMA32: return fa2_launch_mfma32(p);
+    case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4);
+    case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8);
     default: fa2_set_error("unknown kernel variant %d", variant); return FA2_ERR_BAD_ARG;
     }
 }
@@ -146,6 +148,8 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     switch (v) {
     case FA2_VARIANT_MFMA16: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16_W8: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA16P: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA16P_W8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     default: out4[1] = 16; out4[2] = 64; out4[3] = 4; break;
     }

@@ -51,6 +51,9 @@ extern "C" {
 #define FA2_VARIANT_MFMA16 2  /* f16/bf16, d in {64,128}, unit d-stride; 4 waves x 32 rows         */
 #define FA2_VARIANT_MFMA16_W8 3 /* same, 8 waves x 32 rows (256-row Q tile)                        */
 #define FA2_VARIANT_MFMA32 4  /* f32 via v_mfma_f32_32x32x2_f32, d in {64,128}                     */
+#define FA2_VARIANT_MFMA16P 5 /* f16/bf16 software-pipelined (32-key blocks, QK^T of block j+1 under   */
+                              /* the softmax of block j), 4 waves x 32 rows                         */
+#define FA2_VARIANT_MFMA16P_W8 6 /* same, 8 waves x 32 rows                                         */
 
 /*
  * O = softmax(scale * Q K^T [+ causal mask]) V   and   L = log2-domain log-sum-exp of the scores,
