@@ -88,8 +88,8 @@ def cpu_baseline(c, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of O in the timed step")
@@ -130,6 +130,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # Clock ramp: an idle MI355X runs its first milliseconds of work below its sustained clock (measured:
+    # 751 TFLOP/s with 5 warm-up steps vs 831 with 50 on the same device).  Spin ~0.25 s of the same kernel
+    # before the W untimed warm-up steps so that short (K, W) choices measure the steady state too.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.25:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

@@ -4,6 +4,7 @@
 // pruned by an SRAM heuristic and benchmarked on first use of every (B, H, N, d)).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "fa2_common.h"
@@ -56,10 +57,10 @@ int validate(const Fa2Problem &p) {
 // (B, H, N, d) the choice does not depend on B or H.
 int pick_variant(const Fa2Problem &p) {
     if (fa2_mfma16_supports(p)) {
-        // 8 waves x 32 rows halves the K/V traffic per query row; it needs enough 256-row tiles to
-        // fill 256 CUs, otherwise the 128-row tile spreads the work over more CUs.
+        // Software-pipelined kernel.  8 waves x 32 rows halves the K/V traffic per query row; it needs
+        // enough 256-row tiles to fill 256 CUs, otherwise the 128-row tile spreads the work wider.
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
-        return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
+        return wg256 >= 512 ? FA2_VARIANT_MFMA16P_W8 : FA2_VARIANT_MFMA16P;
     }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;
     return FA2_VARIANT_GENERIC;
@@ -74,8 +75,19 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16: return fa2_launch_mfma16(p, 4);
     case FA2_VARIANT_MFMA16_W8: return fa2_launch_mfma16(p, 8);
     case FA2_VARIANT_MFMA32: return fa2_launch_mfma32(p);
-    case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4);
-    case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8);
+    case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4, 0);
+    case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8, 64);
+    case FA2_VARIANT_MFMA16P + 16: return fa2_launch_mfma16p(p, 4, 1);     // experimental schedules (A/B only)
+    case FA2_VARIANT_MFMA16P_W8 + 16: return fa2_launch_mfma16p(p, 8, 1);
+    case FA2_VARIANT_MFMA16P_W8 + 32: return fa2_launch_mfma16p(p, 8, 2);   // ablations: only in -DFA2_ABLATIONS builds
+    case FA2_VARIANT_MFMA16P_W8 + 64: return fa2_launch_mfma16p(p, 8, 4);
+    case FA2_VARIANT_MFMA16P_W8 + 128: return fa2_launch_mfma16p(p, 8, 8);
+    case FA2_VARIANT_MFMA16P_W8 + 224: return fa2_launch_mfma16p(p, 8, 14);
+    case FA2_VARIANT_MFMA16P_W8 + 256: return fa2_launch_mfma16p(p, 8, 16);
+    case FA2_VARIANT_MFMA16P_W8 + 512: return fa2_launch_mfma16p(p, 8, 32);
+    case FA2_VARIANT_MFMA16P_W8 + 736: return fa2_launch_mfma16p(p, 8, 46);
+    case FA2_VARIANT_MFMA16P_W8 + 1024: return fa2_launch_mfma16p(p, 8, 0);
+    case FA2_VARIANT_MFMA16P + 1024: return fa2_launch_mfma16p(p, 4, 64);
     default: fa2_set_error("unknown kernel variant %d", variant); return FA2_ERR_BAD_ARG;
     }
 }
@@ -103,6 +115,11 @@ void fa2_set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int fa2_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 extern "C" {

@@ -21,11 +21,12 @@ struct Fa2Problem {
 int fa2_launch_generic(const Fa2Problem &p);
 int fa2_launch_mfma16(const Fa2Problem &p, int waves);
 int fa2_launch_mfma32(const Fa2Problem &p);
-int fa2_launch_mfma16p(const Fa2Problem &p, int waves);
+int fa2_launch_mfma16p(const Fa2Problem &p, int waves, int opt);
 bool fa2_mfma16_supports(const Fa2Problem &p);
 bool fa2_mfma32_supports(const Fa2Problem &p);
 
 void fa2_set_error(const char *fmt, ...);
+int fa2_env_int(const char *name, int dflt);  // tuning knobs for A/B runs (read per call)
 
 static inline int fa2_dtype_size(int dt) {
     switch (dt) {
