@@ -77,6 +77,16 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA32: return fa2_launch_mfma32(p);
     case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4, 0);
     case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8, 64);
+    case FA2_VARIANT_MFMA16X: return fa2_launch_mfma16x(p, 0);
+    case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
+    case FA2_VARIANT_MFMA16X + 2048 * 3: return fa2_launch_mfma16x(p, 3);
+    case FA2_VARIANT_MFMA16X + 2048 * 4: return fa2_launch_mfma16x(p, 4);
+    case FA2_VARIANT_MFMA16X + 2048 * 7: return fa2_launch_mfma16x(p, 7);
+    case FA2_VARIANT_MFMA16X + 2048 * 8: return fa2_launch_mfma16x(p, 8);
+    case FA2_VARIANT_MFMA16X + 2048 * 15: return fa2_launch_mfma16x(p, 15);
+    case FA2_VARIANT_MFMA16X + 2048 * 16: return fa2_launch_mfma16x(p, 16);
+    case FA2_VARIANT_MFMA16X + 2048 * 32: return fa2_launch_mfma16x(p, 32);
+    case FA2_VARIANT_MFMA16X + 2048 * 48: return fa2_launch_mfma16x(p, 48);
     case FA2_VARIANT_MFMA16P + 16: return fa2_launch_mfma16p(p, 4, 1);     // experimental schedules (A/B only)
     case FA2_VARIANT_MFMA16P_W8 + 16: return fa2_launch_mfma16p(p, 8, 1);
     case FA2_VARIANT_MFMA16P_W8 + 32: return fa2_launch_mfma16p(p, 8, 2);   // ablations: only in -DFA2_ABLATIONS builds
@@ -167,6 +177,7 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA16_W8: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16P: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16P_W8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA16X: out4[1] = 256; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     default: out4[1] = 16; out4[2] = 64; out4[3] = 4; break;
     }

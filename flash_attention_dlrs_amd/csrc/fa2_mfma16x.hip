@@ -1,0 +1,598 @@
+// fa2_mfma16x.hip -- FA-2 forward for f16 / bf16, d = 128, one wave per SIMD with the whole register file
+// (variant "mfma16x": 4 waves x 64 query rows, 256-row Q tile per workgroup, one workgroup per CU).
+//
+// Arithmetic: the reference's (src/flash_attention_kernels.py:84-108), as in fa2_mfma16p.hip: exp2-domain
+// online softmax in fp32, P rounded RTNE to the I/O dtype before P.V, deferred running-max update.
+//
+// Why this shape.  Ablations of fa2_mfma16p.hip on MI355X (8 waves x 32 rows, two waves per SIMD) showed
+// that with ALL softmax arithmetic removed the MFMA + LDS-operand skeleton still stops at 52 % of the bf16
+// peak: every 32x32x16 MFMA pulls its A operand (a K row fragment or a transposed V fragment) from LDS,
+// 1.5 LDS instructions per MFMA per wave, 8 waves per CU.  Here a wave owns TWO 32-row query blocks and
+// every K / V fragment read from LDS feeds two MFMAs (one per query block), halving LDS traffic and LDS
+// instruction issue per FLOP; with one wave per SIMD the kernel may use up to 512 registers, enough for
+// O (128) + Q (64) + two score tiles per query block (64) + staging and fragments.
+//
+// Schedule per 32-key block j (skewed by one block as in fa2_mfma16p.hip), both query blocks in step:
+//     phase 1:  S_next[qb] = K_blk(j+1) . Q[qb]^T   (16 MFMA)  ||  P_j[qb] = exp2(S_j[qb]*c - m[qb]), row sums, cvt
+//     phase 2:  O[qb]     += V_blk(j)^T . P_j[qb]^T (16 MFMA)  ||  row max of S_next[qb], rescale decision
+// K is staged in 64-row units offset by 32 rows against V (unit u = keys 64u-32 .. 64u+31), padded LDS rows
+// (K +16 B, V +64 B: conflict-free row reads and transposed reads, lane_base + immediate addressing),
+// buffer-load staging with the LDS writes at the top of the next iteration, one barrier per 64 keys.
+#include "fa2_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T *
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<_Float16> {
+    using frag = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct XArgs {
+    const char *Q, *K, *V;
+    char *O, *L;
+    int64_t qs[3], ks[3], vs[3], os[3];  // B, H, N strides in bytes
+    int64_t ls[2];
+    int B, H, N;
+    float c_log2e;
+    int group;
+};
+
+// v_permlane32_swap exchange between the wave's two 32-lane halves (see fa2_mfma16p.hip for the
+// __builtin_bit_cast-on-a-vector-element pitfall that the scalar copies avoid).
+__device__ __forceinline__ void half_swap(float x, float &lo, float &hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a = r[0], b = r[1];
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float half_swap_max(float x) {
+    float lo, hi;
+    half_swap(x, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    float lo, hi;
+    half_swap(x, lo, hi);
+    return lo + hi;
+}
+
+// ABL (timing-only ablations, -DFA2_ABLATIONS builds): 1 = no exp/sum, 2 = no row max, 4 = no LDS operand reads in
+// the steady loop, 8 = no staging (global loads, LDS writes, barrier) in the steady loop.
+template <typename T, bool CAUSAL, int ABL>
+__global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    constexpr int D = 128, NT = 256, BR = 256, QB = 2;
+    constexpr int ROWB = D * 2, CPR = ROWB / 16, CPT = 64 * CPR / NT, RPI = NT / CPR;  // 16 chunks/row, 4/thread, 16 rows/pass
+    constexpr int KROWB = ROWB + 16, VROWB = ROWB + 64;
+    constexpr int KUNIT = 64 * KROWB, VTILE = 64 * VROWB;
+    constexpr int NKB = 3;            // K units in LDS: the one in use, the next (read ahead), the one being written
+    constexpr int VBASE = NKB * KUNIT;  // LDS: Kunit x3 | Vtile0 | Vtile1
+    constexpr int KS = D / 16, DB = D / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS_PTR(char) lds = (LDS_PTR(char))smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int N = a.N;
+
+    const int nq = (N + BR - 1) / BR, nbh = a.B * a.H;
+    int bh, qi;
+    {
+        const int bid = blockIdx.x;
+        if ((nbh & 7) == 0) {  // whole (b, h) groups per XCD: K/V reuse in that XCD's L2 (speed only)
+            const int slot = bid >> 3, G = a.group;
+            const int batch = slot / (G * nq), r = slot - batch * (G * nq);
+            bh = (batch * G + r % G) * 8 + (bid & 7);
+            qi = r / G;
+        } else {
+            bh = bid / nq;
+            qi = bid % nq;
+        }
+        if (CAUSAL) qi = nq - 1 - qi;  // heaviest tiles first
+    }
+    const int b = bh / a.H, hh = bh - b * a.H;
+    const int q0 = qi * BR + wave * 64;  // first row of this wave; query block qb covers q0 + 32 qb .. +31
+
+    const char *Qp = a.Q + (int64_t)b * a.qs[0] + (int64_t)hh * a.qs[1];
+    const char *Kp = a.K + (int64_t)b * a.ks[0] + (int64_t)hh * a.ks[1];
+    const char *Vp = a.V + (int64_t)b * a.vs[0] + (int64_t)hh * a.vs[1];
+
+    frag qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int row = q0 + 32 * qb + i;
+        row = row < N ? row : N - 1;
+        const char *qp = Qp + (int64_t)row * a.qs[2] + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = __builtin_bit_cast(frag, *(const u32x4 *)(qp + ks * 32));
+    }
+
+    // ---- staging (buffer loads; rows past N and the "negative" rows of K unit 0 read as zero)
+    const int st_row = tid / CPR, st_ch = tid % CPR;
+    const int st_k = st_row * KROWB + st_ch * 16, st_v = VBASE + st_row * VROWB + st_ch * 16;
+    const int krs = (int)a.ks[2], vrs = (int)a.vs[2];
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Kp, 0, (N - 1) * krs + ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Vp, 0, (N - 1) * vrs + ROWB, 0x00020000);
+    const int kvo = st_row * krs + st_ch * 16, vvo = st_row * vrs + st_ch * 16;
+
+    const int kend = CAUSAL ? ((qi * BR + BR) < N ? (qi * BR + BR) : N) : N;
+    const int nt = (kend + 63) >> 6;    // V tiles = loop iterations of this workgroup
+    const int nblk = (kend + 31) >> 5;  // 32-key blocks of this workgroup
+    int nb = nblk;                      // ... of this wave: up to the diagonal block of its second query block
+    if (CAUSAL) nb = (q0 >> 5) + 2 < nblk ? (q0 >> 5) + 2 : nblk;
+
+    u32x4 kreg[CPT], vreg[CPT];
+    // tile offsets go into the VGPR offset (range-checked), never into soffset (unsigned, unchecked)
+    auto load_k = [&](int u) {
+        const int base = (u * 64 - 32) * krs + kvo;
+#pragma unroll
+        for (int it = 0; it < CPT; ++it)
+            kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, base + it * RPI * krs, 0, 0));
+    };
+    auto load_v = [&](int t) {
+        const int base = t * 64 * vrs + vvo;
+#pragma unroll
+        for (int it = 0; it < CPT; ++it)
+            vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, base + it * RPI * vrs, 0, 0));
+    };
+    auto load_k1 = [&](int it, int u) {
+        kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, (u * 64 - 32 + it * RPI) * krs + kvo, 0, 0));
+    };
+    auto load_v1 = [&](int it, int t) {
+        vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, (t * 64 + it * RPI) * vrs + vvo, 0, 0));
+    };
+    auto write_k1 = [&](int it, int buf) { *(LDS_PTR(u32x4))(lds + buf * KUNIT + st_k + it * RPI * KROWB) = kreg[it]; };
+    auto write_v1 = [&](int it, int buf) { *(LDS_PTR(u32x4))(lds + buf * VTILE + st_v + it * RPI * VROWB) = vreg[it]; };
+    auto write_k = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) *(LDS_PTR(u32x4))(lds + buf * KUNIT + st_k + it * RPI * KROWB) = kreg[it];
+    };
+    auto write_v = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) *(LDS_PTR(u32x4))(lds + buf * VTILE + st_v + it * RPI * VROWB) = vreg[it];
+    };
+
+    const int kbase = i * KROWB + h * 16;
+    int vbase;
+    {
+        const int w = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+        vbase = VBASE + (4 * h + qq) * VROWB + (2 * w + (pp >> 1)) * 16 + 8 * (pp & 1);
+    }
+
+    f32x16 o[QB][DB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
+    float m[QB] = {-INFINITY, -INFINITY}, lsum[QB] = {0.0f, 0.0f};
+    const float c = a.c_log2e;
+    constexpr float kThr = 8.0f;
+
+    // Register-file steering (one wave per SIMD: 256 arch VGPRs + 256 AGPRs).  Q fragments are only ever MFMA
+    // B operands, which may live in AGPRs; the score tiles are read by the VALU and must not.  Left alone
+    // hipcc does the opposite (scores in AGPRs: one v_accvgpr_read per score element per block).
+    auto pin_q_agpr = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(qf[qb][ks]));
+    };
+    // S^T[qb] = K rows [koff ..] . Q[qb]^T : every K fragment feeds both query blocks
+    auto qk = [&](f32x16 (&s)[QB], int koff) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[qb][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const frag kf = __builtin_bit_cast(frag, *(LDS_PTR(u32x4))(lds + koff + kbase + ks * 32));
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) s[qb] = M::mfma(kf, qf[qb][ks], s[qb]);
+        }
+    };
+    // row max of block j per query block, deferred running-max update (see fa2_mfma16p.hip); returns
+    // whether either query block has to rescale (coeff[qb] == 1 for one that does not).
+    auto partial = [&](f32x16 (&s)[QB], int j, float (&coeff)[QB], bool masked) -> bool {
+        float mx[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (masked) {
+                int lim = N - 1;
+                if (CAUSAL) {
+                    const int qrow = q0 + 32 * qb + i;
+                    lim = qrow < lim ? qrow : lim;
+                }
+                const int klim = lim - (j * 32 + 4 * h);  // key(r) = 32j + 4h + (r&3) + 8(r>>2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) > klim) s[qb][r] = -INFINITY;
+            }
+            float x = fmaxf(s[qb][0], s[qb][1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) x = fmaxf(x, s[qb][r]);
+            mx[qb] = half_swap_max(x) * c;
+        }
+        // a fully masked block (query block 0 on the wave's last block) has mx = -inf: never fires
+        const bool fire = !__all((mx[0] - m[0] <= kThr) && (mx[1] - m[1] <= kThr));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) coeff[qb] = 1.0f;
+        if (fire) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m_new = fmaxf(m[qb], mx[qb]);
+                coeff[qb] = __builtin_amdgcn_exp2f(m[qb] - m_new);
+                m[qb] = m_new;
+            }
+        }
+        return fire;
+    };
+    auto finish = [&](f32x16 (&s)[QB], frag (&pf)[QB][2]) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float rs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][r], c, -m[qb]));
+                rs += p;
+                pf[qb][r >> 3][r & 7] = (T)p;
+            }
+            lsum[qb] += rs;
+        }
+    };
+    // in-place O *= coeff, l *= coeff (rare path; asm keeps the accumulators where they are)
+    auto rescale = [&](bool fire, float (&coeff)[QB]) {
+        if (fire) {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float x = o[qb][db][r];
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(coeff[qb]));
+                        o[qb][db][r] = x;
+                    }
+                lsum[qb] *= coeff[qb];
+            }
+            asm volatile("s_nop 7" ::: "memory");
+        }
+    };
+    // O^T[qb] += V[rows voff ..]^T . P[qb]^T : every V fragment feeds both query blocks
+    auto pv = [&](frag (&pf)[QB][2], int voff) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int off = voff + vbase + ss * 16 * VROWB + db * 64;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + 8 * VROWB));
+                const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[qb][db] = M::mfma(vf, pf[qb][ss], o[qb][db]);
+            }
+    };
+    auto block_masked = [&](int j) { return (CAUSAL && (j * 32 + 31 > q0)) || (j * 32 + 32 > N); };
+
+    // ---- prologue: K units 0..2 and V tile 0 in LDS; (K unit 3, V tile 1) in flight in the staging registers
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    load_k(1);
+    write_k(1);
+    load_k(2);
+    write_k(2);
+    load_k(3);
+    load_v(1);
+    __syncthreads();
+
+    f32x16 sA[QB], sB[QB];
+    float coeffA[QB] = {1.0f, 1.0f}, coeffB[QB] = {1.0f, 1.0f};
+    bool fireA = false, fireB = false;
+    frag pf[QB][2];
+    qk(sA, 32 * KROWB);  // block 0 = rows 32..63 of K unit 0
+    fireA = partial(sA, 0, coeffA, block_masked(0));
+    __syncthreads();     // K unit 0 is overwritten by unit 3 in iteration 0
+
+    int jm = nb;  // first block of this wave that needs a mask
+    if (CAUSAL) jm = (q0 >> 5) < jm ? (q0 >> 5) : jm;
+    if ((N >> 5) < jm) jm = N >> 5;
+    int t_steady = (jm - 1) / 2;
+    t_steady = t_steady < 0 ? 0 : (t_steady > nt ? nt : t_steady);
+
+    // ---- hand-ordered steady-state half iteration: sixteen steps of two MFMAs (one K or V fragment feeding both
+    // query blocks).  Every step also carries (a) the LDS read of the fragment needed TWO steps later, (b) its
+    // share of the softmax arithmetic, (c) on even steps one staging operation (LDS write or global load of the
+    // next K unit / V tile).  A sched_barrier after each step pins the order: left to itself hipcc issues the
+    // 16 QK^T MFMAs back to back and the whole softmax after them, and with ONE wave per SIMD nothing else
+    // covers for a stall.
+    //   steps 0..7  (phase 1): S_nxt[qb] += K[ks] . Q[qb][ks]      exp/sum/cvt of 12 of the 16 element pairs of S_cur
+    //   steps 8..15 (phase 2): O[qb][db] += V[ss][db] . P[qb][ss]  the last 4 pairs (steps 8..11), running max of S_nxt
+    // Operand stream: ops 0..7 = K fragments, ops 8..15 = V fragments, ops 16, 17 = K fragments 0, 1 of the
+    // FOLLOWING half; op n lives in ring[n & 3], step n consumes op n and issues the read of op n+2.
+    auto lds_k = [&](int off) { return __builtin_bit_cast(frag, *(LDS_PTR(u32x4))(lds + off)); };
+    auto lds_v = [&](int off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + 8 * VROWB));
+        return __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto half_iter = [&](f32x16 (&sCur)[QB], f32x16 (&sNxt)[QB], frag (&ring)[4], int koff, int voff, int knext,
+                         float (&coeff)[QB], auto &&staging) -> bool {
+        auto issue = [&](int n) {  // n is a compile-time constant at every call site (unrolled loops)
+            if constexpr (ABL & 4) return;
+            if (n < 8) ring[n & 3] = lds_k(koff + kbase + n * 32);
+            else if (n < 16) ring[n & 3] = lds_v(voff + vbase + ((n - 8) >> 2) * 16 * VROWB + ((n - 8) & 3) * 64);
+            else ring[n & 3] = lds_k(knext + kbase + (n - 16) * 32);
+        };
+        constexpr int PD = 3;  // read-ahead distance in steps; the ring holds ops n .. n+PD
+        float rs[QB] = {0.0f, 0.0f};
+        // element pair q = 0..15: query block q & 1, elements 2(q>>1), 2(q>>1)+1.  Pairs 0..7 (P of keys 0..15,
+        // both query blocks) are due before step 8, all of them before step 12.
+        auto do_pair = [&](int q) {
+            const int qb = q & 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * (q >> 1) + e;
+                float p;
+                if constexpr (ABL & 1) p = sCur[qb][r];
+                else {
+                    p = __builtin_amdgcn_exp2f(__builtin_fmaf(sCur[qb][r], c, -m[qb]));
+                    rs[qb] += p;
+                }
+                pf[qb][r >> 3][r & 7] = (T)p;
+            }
+        };
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            issue(ks + PD);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (ks == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    sNxt[qb] = M::mfma(ring[0], qf[qb][0], z);
+                } else {
+                    sNxt[qb] = M::mfma(ring[ks & 3], qf[qb][ks], sNxt[qb]);
+                }
+            }
+            do_pair(ks + (ks + 1) / 2);                       // steps 0..7 take 2,1,2,1,2,1,2,1 pairs: 0..11
+            if ((ks & 1) == 0) do_pair(ks + (ks + 1) / 2 + 1);
+            staging(ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx[QB];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int ss = st >> 2, db = st & 3;
+            issue(8 + st + PD);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o[qb][db] = M::mfma(ring[(8 + st) & 3], pf[qb][ss], o[qb][db]);
+            if (st < 4) do_pair(12 + st);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if constexpr (ABL & 2) {
+                    if (st == 0) mx[qb] = sNxt[qb][0];
+                } else {
+                    const float x = fmaxf(sNxt[qb][2 * st], sNxt[qb][2 * st + 1]);
+                    mx[qb] = st == 0 ? x : fmaxf(mx[qb], x);
+                }
+            }
+            staging(8 + st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) lsum[qb] += rs[qb];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mx[qb] = half_swap_max(mx[qb]) * c;
+        const bool fire = !__all((mx[0] - m[0] <= kThr) && (mx[1] - m[1] <= kThr));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) coeff[qb] = 1.0f;
+        if (fire) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m_new = fmaxf(m[qb], mx[qb]);
+                coeff[qb] = __builtin_amdgcn_exp2f(m[qb] - m_new);
+                m[qb] = m_new;
+            }
+        }
+        return fire;
+    };
+
+    // K unit u lives in ring buffer u % 3: kb1 -> unit t+1 (in use), kb2 -> unit t+2 (published, read ahead at the
+    // end of the iteration), kb3 -> unit t+3 (written during iteration t from the staging registers).
+    int t = 0, kb1 = 1, kb2 = 2, kb3 = 0;
+    if (t_steady > 0) {
+        frag ring[4];
+        ring[0] = lds_k(KUNIT + kbase);       // K fragments 0..2 of block 1 (rows 0..31 of K unit 1)
+        ring[1] = lds_k(KUNIT + kbase + 32);
+        ring[2] = lds_k(KUNIT + kbase + 64);
+        for (; t < t_steady; ++t) {
+            pin_q_agpr();
+            const int kcur = kb1 * KUNIT;      // K unit t+1: rows 0..31 = block 2t+1, rows 32..63 = block 2t+2
+            const int vcur = (t & 1) * VTILE;  // V tile t:   rows 0..31 = block 2t,   rows 32..63 = block 2t+1
+            const int vwr = (t + 1) & 1;
+            // first half: the staging registers (K unit t+3, V tile t+1) go to LDS, one 16-byte chunk per step 0..7,
+            // and are refilled at once (steps 8..15) with the loads of (K unit t+4, V tile t+2): those have almost a
+            // whole iteration (~1 us) to land -- with the loads in the second half (~0.5 us ahead) the vmcnt wait in
+            // front of the next iteration's first LDS write stalled the SIMD's only wave (-19 %)
+            auto stage_wr = [&](int n) {
+                if constexpr (ABL & 8) return;
+                if (n < 4) write_k1(n, kb3);
+                else if (n < 8) write_v1(n - 4, vwr);
+                else {
+                    if constexpr (ABL & 32) return;
+                    if (n < 12) load_k1(n - 8, t + 4);
+                    else load_v1(n - 12, t + 2);
+                }
+            };
+            auto stage_ld = [&](int) {};
+            rescale(fireA, coeffA);
+            fireB = half_iter(sA, sB, ring, kcur, vcur, kcur + 32 * KROWB, coeffB, stage_wr);
+            rescale(fireB, coeffB);
+            // ops 16, 17 of this half = K fragments 0, 1 of block 2t+3 = rows 0..31 of unit t+2 (published during
+            // iteration t-1): the next iteration starts with its operands already in registers
+            fireA = half_iter(sB, sA, ring, kcur + 32 * KROWB, vcur + 32 * VROWB, kb2 * KUNIT, coeffA, stage_ld);
+            if constexpr (!(ABL & (8 | 16))) __syncthreads();   // ABL 16: no barrier only
+            const int k0 = kb1;
+            kb1 = kb2;
+            kb2 = kb3;
+            kb3 = k0;
+        }
+    }
+    for (; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) {
+            write_k(kb3);
+            write_v((t + 1) & 1);
+            load_k(t + 4);
+            load_v(t + 2);
+        }
+        const int kcur = kb1 * KUNIT;
+        const int vcur = (t & 1) * VTILE;
+        const int jA = 2 * t, jB = 2 * t + 1, jA2 = 2 * t + 2;
+        if (jA < nb) rescale(fireA, coeffA);
+        if (jB < nb) qk(sB, kcur);
+        if (jA < nb) {
+            finish(sA, pf);
+            pv(pf, vcur);
+        }
+        if (jB < nb) {
+            fireB = partial(sB, jB, coeffB, block_masked(jB));
+            rescale(fireB, coeffB);
+        }
+        if (jA2 < nb) qk(sA, kcur + 32 * KROWB);
+        if (jB < nb) {
+            finish(sB, pf);
+            pv(pf, vcur + 32 * VROWB);
+        }
+        if (jA2 < nb) fireA = partial(sA, jA2, coeffA, block_masked(jA2));
+        __syncthreads();
+        const int k0 = kb1;
+        kb1 = kb2;
+        kb2 = kb3;
+        kb3 = k0;
+    }
+
+    // ---- epilogue (kernels.py:105-108)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = q0 + 32 * qb + i;
+        const float l = half_swap_sum(lsum[qb]);
+        const float inv = 1.0f / l;
+        if (qrow < N) {
+            char *op = a.O + (int64_t)b * a.os[0] + (int64_t)hh * a.os[1] + (int64_t)qrow * a.os[2] + h * 8;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef __attribute__((ext_vector_type(4))) T Tx4;
+                    Tx4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (T)(o[qb][db][4 * g + j] * inv);
+                    *(u32x2 *)(op + db * 64 + g * 16) = __builtin_bit_cast(u32x2, v);
+                }
+            if (h == 0) {
+                T *lp = (T *)a.L + b * a.ls[0] + hh * a.ls[1] + qrow;
+                *lp = (T)(m[qb] + __builtin_amdgcn_logf(l));
+            }
+        }
+    }
+}
+
+template <typename T, int ABL> int launch_t(const Fa2Problem &p, const XArgs &a) {
+    const long long nblk = (long long)((p.N + 255) / 256) * p.B * p.H;
+    if (nblk > 0x7fffffffLL) {
+        fa2_set_error("mfma16x: grid too large");
+        return FA2_ERR_BAD_ARG;
+    }
+    const dim3 grid((unsigned)nblk), block(256);
+    constexpr size_t smem = 3 * 64 * (128 * 2 + 16) + 2 * 64 * (128 * 2 + 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)fa2_fwd_mfma16x_kernel<T, true, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void *)fa2_fwd_mfma16x_kernel<T, false, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    if (p.causal)
+        hipLaunchKernelGGL((fa2_fwd_mfma16x_kernel<T, true, ABL>), grid, block, smem, p.stream, a);
+    else
+        hipLaunchKernelGGL((fa2_fwd_mfma16x_kernel<T, false, ABL>), grid, block, smem, p.stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fa2_set_error("mfma16x kernel launch failed: %s", hipGetErrorString(e));
+        return FA2_ERR_LAUNCH;
+    }
+    return FA2_OK;
+}
+
+}  // namespace
+
+int fa2_launch_mfma16x(const Fa2Problem &p, int abl) {
+    const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31);
+    if (!fa2_mfma16_supports(p) || p.d != 128 || !fits32) {
+        fa2_set_error("mfma16x kernel: needs f16/bf16, d = 128, unit d-stride, 16-byte aligned rows, scale > 0, "
+                      "N * row stride < 2 GiB");
+        return FA2_ERR_UNSUPPORTED;
+    }
+    XArgs a;
+    a.Q = (const char *)p.Q; a.K = (const char *)p.K; a.V = (const char *)p.V;
+    a.O = (char *)p.O; a.L = (char *)p.L;
+    for (int k = 0; k < 3; ++k) {
+        a.qs[k] = p.qs[k] * 2; a.ks[k] = p.ks[k] * 2; a.vs[k] = p.vs[k] * 2; a.os[k] = p.os[k] * 2;
+    }
+    a.ls[0] = p.ls[0]; a.ls[1] = p.ls[1];
+    a.B = p.B; a.H = p.H; a.N = p.N;
+    a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
+    a.group = 1;
+    if (p.causal && ((p.B * p.H) & 7) == 0) {
+        const int per_xcd = p.B * p.H / 8;
+        int g = fa2_env_int("FA2_CAUSAL_GROUP", 2);
+        g = g < 1 ? 1 : (g > per_xcd ? per_xcd : g);
+        while (per_xcd % g) --g;
+        a.group = g;
+    }
+#ifdef FA2_ABLATIONS
+    if (p.dtype == FA2_DTYPE_BF16) switch (abl) {
+        case 1: return launch_t<__bf16, 1>(p, a);
+        case 3: return launch_t<__bf16, 3>(p, a);
+        case 4: return launch_t<__bf16, 4>(p, a);
+        case 7: return launch_t<__bf16, 7>(p, a);
+        case 8: return launch_t<__bf16, 8>(p, a);
+        case 15: return launch_t<__bf16, 15>(p, a);
+        case 16: return launch_t<__bf16, 16>(p, a);
+        case 32: return launch_t<__bf16, 32>(p, a);
+        case 48: return launch_t<__bf16, 48>(p, a);
+        default: break;
+        }
+#endif
+    if (abl != 0) {
+        fa2_set_error("mfma16x: ablation %d not built", abl);
+        return FA2_ERR_UNSUPPORTED;
+    }
+    return p.dtype == FA2_DTYPE_BF16 ? launch_t<__bf16, 0>(p, a) : launch_t<_Float16, 0>(p, a);
+}
