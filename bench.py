@@ -85,6 +85,23 @@ def cpu_baseline(c, budget_s=12.0):
     return out
 
 
+def profiled_traffic(config, variant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this very
+    command (profiles/rNN/<config>_*_rocprof.json: FETCH_SIZE x 1024 x 2 -- the gfx950 half-count correction of
+    MI355X_MICROARCH.md section HBM -- plus WRITE_SIZE x 1024; collected in separate --pmc passes by
+    scripts/gpu_prof.sh).  bench.py cannot collect PMC counters itself; None if no summary is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{config}_*_rocprof.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            best = (d["hbm_bytes_per_launch"]["total"], os.path.relpath(f, ROOT))
+        except Exception:
+            continue
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +215,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(c)
 
+    traffic = profiled_traffic(args.config, variant) if args.variant == "auto" else None
     if rank == 0:
         out = {
             "metric": "attention fwd TFLOP/s per GPU (B=4,H=32,N=4096,d=128 bf16); % MFMA peak",
@@ -211,7 +229,9 @@ def main():
                        "sharding": "heads" if world > 1 else "none",
                        "flops_per_step_per_gpu": F, "pct_of_mfma_peak": round(100 * value / world / peak, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
+                         "algorithmic_bytes": (4 * c["d"] + 1) * c["B"] * c["H"] * c["N"] * Q.element_size(),
                          "kernel_ms_avg": round(kern_avg, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
                          "kernel_ms_min": round(kern_ms[0], 5)},
             "cpu_baseline": cpu,
