@@ -35,6 +35,8 @@ CONFIGS = {  # BASELINE.json "configs"
     "c3_noncausal": dict(B=4, H=32, N=4096, d=128, dtype="bf16", causal=False),
     "c4_per_gpu": dict(B=8, H=8, N=8192, d=128, dtype="bf16", causal=False),
     "ref_test": dict(B=32, H=32, N=256, d=128, dtype="f32", causal=False),  # src/test_correctness.py:9-14
+    "f32_long": dict(B=2, H=16, N=4096, d=128, dtype="f32", causal=False),
+    "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
 }
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
 # Dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (TFLOP/s)

@@ -14,16 +14,16 @@ LIB_PATH = os.environ.get("FA2_HIP_LIB") or os.path.join(_HERE, "libfa2_hip.so")
 
 FA2_DTYPE_F32, FA2_DTYPE_F16, FA2_DTYPE_BF16, FA2_DTYPE_F8E5M2, FA2_DTYPE_F8E4M3, FA2_DTYPE_F64 = range(6)
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA16, VARIANT_MFMA16_W8, VARIANT_MFMA32, VARIANT_MFMA16P, \
-    VARIANT_MFMA16P_W8, VARIANT_MFMA16X = range(8)
+    VARIANT_MFMA16P_W8, VARIANT_MFMA16X, VARIANT_MFMA16D, VARIANT_MFMA16D_W4 = range(10)
 VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_MFMA16,
             "mfma16_w8": VARIANT_MFMA16_W8, "mfma32": VARIANT_MFMA32, "mfma16p": VARIANT_MFMA16P,
-            "mfma16p_w8": VARIANT_MFMA16P_W8, "mfma16x": VARIANT_MFMA16X, "mfma16p_x1": VARIANT_MFMA16P + 16,
+            "mfma16p_w8": VARIANT_MFMA16P_W8, "mfma16x": VARIANT_MFMA16X, "mfma16d": VARIANT_MFMA16D, "mfma16d_w4": VARIANT_MFMA16D_W4, "mfma16p_x1": VARIANT_MFMA16P + 16,
             "mfma16p_w8_x1": VARIANT_MFMA16P_W8 + 16,
             # timing-only ablations, present only in -DFA2_ABLATIONS builds of the library
             "abl_noexp": VARIANT_MFMA16P_W8 + 32, "abl_nosum": VARIANT_MFMA16P_W8 + 64,
             "abl_nomax": VARIANT_MFMA16P_W8 + 128, "abl_all": VARIANT_MFMA16P_W8 + 224,
             "abl_nobar": VARIANT_MFMA16P_W8 + 256, "abl_noload": VARIANT_MFMA16P_W8 + 512,
-            "abl_skeleton": VARIANT_MFMA16P_W8 + 736,
+            "abl_skeleton": VARIANT_MFMA16P_W8 + 736, "abl_nobar_only": VARIANT_MFMA16P_W8 + 192 * 16,
             "mfma16p_w8_x2": VARIANT_MFMA16P_W8 + 1024, "mfma16p_x2": VARIANT_MFMA16P + 1024,
             "x_noexp": VARIANT_MFMA16X + 2048 * 1, "x_nosoftmax": VARIANT_MFMA16X + 2048 * 3,
             "x_nolds": VARIANT_MFMA16X + 2048 * 4, "x_mfma_only": VARIANT_MFMA16X + 2048 * 7,

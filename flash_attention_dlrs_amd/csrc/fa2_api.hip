@@ -57,10 +57,13 @@ int validate(const Fa2Problem &p) {
 // (B, H, N, d) the choice does not depend on B or H.
 int pick_variant(const Fa2Problem &p) {
     if (fa2_mfma16_supports(p)) {
-        // Software-pipelined kernel.  8 waves x 32 rows halves the K/V traffic per query row; it needs
-        // enough 256-row tiles to fill 256 CUs, otherwise the 128-row tile spreads the work wider.
+        // Software-pipelined kernel with LDS-DMA staging.  8 waves x 32 rows halves the K/V traffic per query
+        // row; it needs enough 256-row tiles to fill 256 CUs, otherwise the 128-row tile spreads the work wider.
+        // (N * row stride >= 2 GiB does not fit the 32-bit buffer offsets: fall back to the first MFMA kernel.)
+        const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31);
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
-        return wg256 >= 512 ? FA2_VARIANT_MFMA16P_W8 : FA2_VARIANT_MFMA16P;
+        if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
+        return wg256 >= 512 ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16D_W4;
     }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;
     return FA2_VARIANT_GENERIC;
@@ -78,6 +81,8 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4, 0);
     case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8, 64);
     case FA2_VARIANT_MFMA16X: return fa2_launch_mfma16x(p, 0);
+    case FA2_VARIANT_MFMA16D: return fa2_launch_mfma16d(p, 8);
+    case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
     case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
     case FA2_VARIANT_MFMA16X + 2048 * 3: return fa2_launch_mfma16x(p, 3);
     case FA2_VARIANT_MFMA16X + 2048 * 4: return fa2_launch_mfma16x(p, 4);
@@ -96,6 +101,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16P_W8 + 256: return fa2_launch_mfma16p(p, 8, 16);
     case FA2_VARIANT_MFMA16P_W8 + 512: return fa2_launch_mfma16p(p, 8, 32);
     case FA2_VARIANT_MFMA16P_W8 + 736: return fa2_launch_mfma16p(p, 8, 46);
+    case FA2_VARIANT_MFMA16P_W8 + 192 * 16: return fa2_launch_mfma16p(p, 8, 192);
     case FA2_VARIANT_MFMA16P_W8 + 1024: return fa2_launch_mfma16p(p, 8, 0);
     case FA2_VARIANT_MFMA16P + 1024: return fa2_launch_mfma16p(p, 4, 64);
     default: fa2_set_error("unknown kernel variant %d", variant); return FA2_ERR_BAD_ARG;
@@ -178,6 +184,8 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA16P: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16P_W8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16X: out4[1] = 256; out4[2] = 32; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA16D: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     default: out4[1] = 16; out4[2] = 64; out4[3] = 4; break;
     }

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16p_kernel(const PipeA
                     write_k(t & 1);        // K unit t+2 replaces unit t (last read in iteration t-1)
                     write_v((t + 1) & 1);  // V tile t+1 replaces tile t-1
                 }
-                __syncthreads();
+                if constexpr (!(OPT & 128)) __syncthreads();   // OPT 128: timing-only ablation, barrier only
             }
         }
     }
@@ -513,6 +513,7 @@ template <typename T> int launch_o(const Fa2Problem &p, const PipeArgs &a, int w
     case 16: return launch_d<T, 16>(p, a, waves);
     case 32: return launch_d<T, 32>(p, a, waves);
     case 46: return launch_d<T, 46>(p, a, waves);
+    case 192: return launch_d<T, 192>(p, a, waves);
 #endif
     default: fa2_set_error("mfma16p: schedule option %d not built", opt); return FA2_ERR_UNSUPPORTED;
     }

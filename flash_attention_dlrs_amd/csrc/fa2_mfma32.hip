@@ -37,7 +37,9 @@ struct Mfma32Args {
 template <int D> __device__ __forceinline__ int lds_off32(int row, int ch) { return row * (D * 4) + ((ch ^ (row & 15)) << 4); }
 
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void fa2_fwd_mfma32_kernel(const Mfma32Args a) {
+// d = 128 needs Q (64) + O (64) + S (16) + staging (32) + fragments > 256 registers: one workgroup per CU there
+// (with two, 61 registers spilled and Q was re-read from scratch every tile: 40 % of the fp32 MFMA peak).
+__global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel(const Mfma32Args a) {
     constexpr int NW = 4, NT = 256, BR = 128, BC = 32;
     constexpr int ROWB = D * 4, TILEB = BC * ROWB, CPR = ROWB / 16, CPT = BC * CPR / NT, RPI = NT / CPR;
     constexpr int NC = D / 8;   // 16-byte Q/K chunks per lane (4 k-steps each)

@@ -54,6 +54,8 @@ extern "C" {
 #define FA2_VARIANT_MFMA16P 5 /* f16/bf16 software-pipelined (32-key blocks, QK^T of block j+1 under   */
                               /* the softmax of block j), 4 waves x 32 rows                         */
 #define FA2_VARIANT_MFMA16P_W8 6 /* same, 8 waves x 32 rows                                         */
+#define FA2_VARIANT_MFMA16D 8 /* MFMA16P_W8 with LDS-DMA staging (buffer_load ... lds), 8 waves x 32 rows  */
+#define FA2_VARIANT_MFMA16D_W4 9 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA16X 7 /* f16/bf16, d = 128: 4 waves x 64 rows, one wave per SIMD, every K/V    */
                               /* fragment read from LDS feeds two MFMAs                              */
 

@@ -41,7 +41,7 @@ def hip_forward(Q, K, V, causal=False, scale=1.0, variant="auto"):
 def supported_variants(dtype, d):
     v = ["auto", "generic"]
     if dtype in (torch.float16, torch.bfloat16) and d in (64, 128):
-        v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2"]
+        v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2", "mfma16d", "mfma16d_w4"]
         if d == 128:
             v += ["mfma16x"]
     if dtype == torch.float32 and d in (64, 128):
