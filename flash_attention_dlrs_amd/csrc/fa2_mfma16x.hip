@@ -189,7 +189,11 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
             for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.0f;
     float m[QB] = {-INFINITY, -INFINITY}, lsum[QB] = {0.0f, 0.0f};
     const float c = a.c_log2e;
-    constexpr float kThr = 8.0f;
+    // Rescale threshold in log2 units: P may reach 2^kThr before the running max is raised.  bf16 P has the
+    // fp32 exponent range (24 leaves 2^24 * N far below fp32 overflow in l and O); f16 P must stay below 65504.
+    // On N(0,1) inputs at scale 1 (score sigma ~ 16 log2 units) a threshold of 8 still fired ~20 times per wave
+    // and 4096 keys -- each time the whole workgroup waits at the next barrier -- 24 makes it rare.
+    constexpr float kThr = sizeof(T) == 2 && __is_same(T, _Float16) ? 12.0f : 24.0f;
 
     // Register-file steering (one wave per SIMD: 256 arch VGPRs + 256 AGPRs).  Q fragments are only ever MFMA
     // B operands, which may live in AGPRs; the score tiles are read by the VALU and must not.  Left alone

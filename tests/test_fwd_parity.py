@@ -7,8 +7,9 @@ size-independent properties there.
 Tolerances (stated once):
   fp32      allclose(atol=1e-4, rtol=1e-5)  -- the reference's own bar (test_correctness.py:40);
             max-abs <= 1e-3 (north_star)
-  fp16      |O - ref| <= 4e-3   (P and O carry 11 significant bits, |O| < 4)
-  bf16      |O - ref| <= 3e-2   (8 significant bits)
+  fp16      |O - ref| <= 6e-3   (P and O carry 11 significant bits; 1.5 ulp of an |O| in [4, 8))
+  bf16      |O - ref| <= 5e-2   (8 significant bits; 1.5 ulp of an |O| in [4, 8): the oracle and the kernel each
+            round P relative to their own running max and round O once more)
   fp8       >= 95 % of elements equal to the oracle's fp8 value, the rest within one fp8 ulp
   L         fp32 5e-5 * max(1,|L|) ; fp16/bf16 one ulp of the dtype at |L|
 """
@@ -26,7 +27,7 @@ import flash_attention_dlrs_amd as fa  # noqa: E402
 from flash_attention_dlrs_amd import _lib  # noqa: E402
 
 DEV = torch.device("cuda:0")
-O_TOL = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2, torch.float64: 1e-9}
+O_TOL = {torch.float32: 1e-4, torch.float16: 6e-3, torch.bfloat16: 5e-2, torch.float64: 1e-9}
 ORACLE_NAME = {torch.float32: "float32", torch.float16: "float16", torch.bfloat16: "bfloat16",
                torch.float64: "float64", torch.float8_e5m2: "float8_e5m2", torch.float8_e4m3fn: "float8_e4m3fn"}
 
