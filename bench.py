@@ -37,10 +37,13 @@ CONFIGS = {  # BASELINE.json "configs"
     "ref_test": dict(B=32, H=32, N=256, d=128, dtype="f32", causal=False),  # src/test_correctness.py:9-14
     "f32_long": dict(B=2, H=16, N=4096, d=128, dtype="f32", causal=False),
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
+    "c3_fp8": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=True),
+    "c5_per_gpu": dict(B=16, H=8, N=16384, d=128, dtype="fp8", causal=False),   # BASELINE.json configs[4], one GPU's head shard
 }
-TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "fp8": torch.float8_e4m3fn}
 # Dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (TFLOP/s)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3, "fp8": 5000.0}  # fp8: the block-scaled MX rate; the non-scaled
+# v_mfma_f32_32x32x16_fp8_fp8 used here runs at the bf16 rate (2500)
 
 
 def flops(c):
@@ -180,7 +183,7 @@ def main():
     value = world * F / (el / args.steps) / 1e12
     peak = PEAK_TFLOPS[c["dtype"]]
     achieved = F / (kern_avg * 1e-3) / 1e12
-    tile = _lib.query_tile(c["N"], c["d"], {"bf16": 2, "fp16": 1, "f32": 0}[c["dtype"]], c["causal"])
+    tile = _lib.query_tile(c["N"], c["d"], {"bf16": 2, "fp16": 1, "f32": 0, "fp8": 4}[c["dtype"]], c["causal"])
 
     extras = {}
     if not args.no_extras:

@@ -29,8 +29,8 @@ def main():
         if cfg not in data:
             c = CONFIGS[cfg]
             torch.manual_seed(42)
-            data[cfg] = tuple(torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev).to(TORCH_DTYPE[c["dtype"]])
-                              for _ in range(3))
+            data[cfg] = tuple((torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev) *
+                               (0.5 if c["dtype"] == "fp8" else 1.0)).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
     res = {f"{c}:{v}": [] for c, v in pairs}
     for cfg, var in pairs:  # warm-up
         Q, K, V = data[cfg]

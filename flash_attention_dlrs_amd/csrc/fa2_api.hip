@@ -65,6 +65,10 @@ int pick_variant(const Fa2Problem &p) {
         if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
         return wg256 >= 512 ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16D_W4;
     }
+    if (fa2_mfma8_supports(p)) {
+        const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
+        return wg256 >= 512 ? FA2_VARIANT_MFMA8 : FA2_VARIANT_MFMA8_W4;
+    }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;
     return FA2_VARIANT_GENERIC;
 }
@@ -81,6 +85,8 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4, 0);
     case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8, 64);
     case FA2_VARIANT_MFMA16X: return fa2_launch_mfma16x(p, 0);
+    case FA2_VARIANT_MFMA8: return fa2_launch_mfma8(p, 8);
+    case FA2_VARIANT_MFMA8_W4: return fa2_launch_mfma8(p, 4);
     case FA2_VARIANT_MFMA16D: return fa2_launch_mfma16d(p, 8);
     case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
     case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
@@ -184,6 +190,8 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA16P: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16P_W8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16X: out4[1] = 256; out4[2] = 32; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16D: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;

@@ -56,6 +56,8 @@ extern "C" {
 #define FA2_VARIANT_MFMA16P_W8 6 /* same, 8 waves x 32 rows                                         */
 #define FA2_VARIANT_MFMA16D 8 /* MFMA16P_W8 with LDS-DMA staging (buffer_load ... lds), 8 waves x 32 rows  */
 #define FA2_VARIANT_MFMA16D_W4 9 /* same, 4 waves x 32 rows                                          */
+#define FA2_VARIANT_MFMA8 10  /* fp8 (e4m3fn / e5m2), d = 128, v_mfma_f32_32x32x16_fp8_fp8 / bf8_bf8; 8 waves    */
+#define FA2_VARIANT_MFMA8_W4 11 /* same, 4 waves x 32 rows                                            */
 #define FA2_VARIANT_MFMA16X 7 /* f16/bf16, d = 128: 4 waves x 64 rows, one wave per SIMD, every K/V    */
                               /* fragment read from LDS feeds two MFMAs                              */
 
