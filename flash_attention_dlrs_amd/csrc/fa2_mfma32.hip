@@ -159,12 +159,12 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);                 // :93
-            const float coeff = exp2f(m - m_new);             // :95
+            const float coeff = __builtin_amdgcn_exp2f(m - m_new);  // :95 (v_exp_f32: 1 ulp, results below 2^-126 flush)
             m = m_new;
             float rs = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[r] - m_new);          // :94
+                const float p = __builtin_amdgcn_exp2f(s[r] - m_new);  // :94
                 s[r] = p;
                 rs += p;
             }
@@ -176,15 +176,33 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel
                     for (int r = 0; r < 16; ++r) o[db][r] *= coeff;  // :97
             }
             // O^T += V^T P^T: k-step r uses accumulator register r as B; A = V[key_r + 4h][32db + i].
+            // The V operands are read in groups of 4 k-steps, one group AHEAD of the MFMAs that consume them
+            // (left to itself hipcc issues each ds_read_b32 right in front of its MFMA: every MFMA then waits
+            // out an LDS round trip and this phase runs at half rate).  sched_barrier pins the order.
+            float vf[2][4][DB];
+            auto load_group = [&](int g) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * g + rr;
+                    const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int col = 32 * db + i;
-                    const float vf = *(LDS_PTR(float))(lds + 2 * TILEB + cur * TILEB + lds_off32<D>(key, col >> 2) + (col & 3) * 4);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[db], 0, 0, 0);  // :98
+                    for (int db = 0; db < DB; ++db) {
+                        const int col = 32 * db + i;
+                        vf[g & 1][rr][db] = *(LDS_PTR(float))(lds + 2 * TILEB + cur * TILEB + lds_off32<D>(key, col >> 2) + (col & 3) * 4);
+                    }
                 }
+            };
+            load_group(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) load_group(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[g & 1][rr][db], s[4 * g + rr], o[db], 0, 0, 0);  // :98
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (more) stage_write(cur ^ 1);
