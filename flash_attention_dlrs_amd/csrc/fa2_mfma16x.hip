@@ -15,9 +15,10 @@
 // Schedule per 32-key block j (skewed by one block as in fa2_mfma16p.hip), both query blocks in step:
 //     phase 1:  S_next[qb] = K_blk(j+1) . Q[qb]^T   (16 MFMA)  ||  P_j[qb] = exp2(S_j[qb]*c - m[qb]), row sums, cvt
 //     phase 2:  O[qb]     += V_blk(j)^T . P_j[qb]^T (16 MFMA)  ||  row max of S_next[qb], rescale decision
-// K is staged in 64-row units offset by 32 rows against V (unit u = keys 64u-32 .. 64u+31), padded LDS rows
-// (K +16 B, V +64 B: conflict-free row reads and transposed reads, lane_base + immediate addressing),
-// buffer-load staging with the LDS writes at the top of the next iteration, one barrier per 64 keys.
+// K is staged in 64-row units offset by 32 rows against V (unit u = keys 64u-32 .. 64u+31), three K units and two
+// V tiles in LDS, filled by LDS-DMA (buffer_load ... lds, inline asm as in fa2_mfma16d.hip: source-side XOR swizzle of
+// the 16-byte chunks, conflict-free row and transposed reads), one DMA piece per even step of the first half
+// iteration, one barrier per 64 keys.
 #include "fa2_common.h"
 
 namespace {
@@ -76,15 +77,29 @@ __device__ __forceinline__ float half_swap_sum(float x) {
     return lo + hi;
 }
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// one 1-KiB LDS-DMA piece (see fa2_mfma16d.hip: inline asm on purpose; our own vmcnt wait before the barrier)
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_base, int voffset) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(voffset), "s"(rsrc)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16-byte chunk swizzle of a 256-byte row (function of row & 15), fa2_mfma16.hip lds_off()
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int lds_off(int row, int ch) { return row * 256 + ((ch ^ swz(row)) << 4); }
+
 // ABL (timing-only ablations, -DFA2_ABLATIONS builds): 1 = no exp/sum, 2 = no row max, 4 = no LDS operand reads in
 // the steady loop, 8 = no staging (global loads, LDS writes, barrier) in the steady loop.
 template <typename T, bool CAUSAL, int ABL>
 __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) {
     using M = Mma<T>;
     using frag = typename M::frag;
-    constexpr int D = 128, NT = 256, BR = 256, QB = 2;
-    constexpr int ROWB = D * 2, CPR = ROWB / 16, CPT = 64 * CPR / NT, RPI = NT / CPR;  // 16 chunks/row, 4/thread, 16 rows/pass
-    constexpr int KROWB = ROWB + 16, VROWB = ROWB + 64;
+    constexpr int D = 128, BR = 256, QB = 2;
+    constexpr int ROWB = D * 2;
+    constexpr int KROWB = ROWB, VROWB = ROWB;  // plain rows: the DMA writes lane-linearly, swizzle instead of padding
     constexpr int KUNIT = 64 * KROWB, VTILE = 64 * VROWB;
     constexpr int NKB = 3;            // K units in LDS: the one in use, the next (read ahead), the one being written
     constexpr int VBASE = NKB * KUNIT;  // LDS: Kunit x3 | Vtile0 | Vtile1
@@ -92,7 +107,8 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LDS_PTR(char) lds = (LDS_PTR(char))smem;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int N = a.N;
 
@@ -128,13 +144,45 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
         for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = __builtin_bit_cast(frag, *(const u32x4 *)(qp + ks * 32));
     }
 
-    // ---- staging (buffer loads; rows past N and the "negative" rows of K unit 0 read as zero)
-    const int st_row = tid / CPR, st_ch = tid % CPR;
-    const int st_k = st_row * KROWB + st_ch * 16, st_v = VBASE + st_row * VROWB + st_ch * 16;
+    // ---- LDS-DMA staging: piece p of a unit/tile = rows 4p .. 4p+3 (1 KiB); wave w issues pieces w, w+4, w+8, w+12.
+    // Lane l fills (row 4p + l/16, slot l%16) with global chunk slot ^ swz(row).  Rows past N and the "negative"
+    // rows of K unit 0 are zero-filled by the descriptor's range check (offsets in the VGPR operand).
+    constexpr int PPW = 4;
     const int krs = (int)a.ks[2], vrs = (int)a.vs[2];
-    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Kp, 0, (N - 1) * krs + ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Vp, 0, (N - 1) * vrs + ROWB, 0x00020000);
-    const int kvo = st_row * krs + st_ch * 16, vvo = st_row * vrs + st_ch * 16;
+    auto make_rsrc = [&](const char *base, int bytes) {
+        const uint64_t ba = (uint64_t)base;
+        i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)ba);
+        r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(ba >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane(bytes);
+        r[3] = 0x00020000;
+        return r;
+    };
+    const i32x4 krsrc = make_rsrc(Kp, (N - 1) * krs + ROWB);
+    const i32x4 vrsrc = make_rsrc(Vp, (N - 1) * vrs + ROWB);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+    int kvo[PPW], vvo[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int row = 4 * (wave + 4 * pp) + (lane >> 4), slot = lane & 15;
+        const int chunk = slot ^ swz(row);
+        kvo[pp] = row * krs + chunk * 16;
+        vvo[pp] = row * vrs + chunk * 16;
+    }
+    auto dma_k1 = [&](int pp, int u, int buf) {
+        dma16(krsrc, lds_base + buf * KUNIT + (wave + 4 * pp) * 1024, kvo[pp] + (u * 64 - 32) * krs);
+    };
+    auto dma_v1 = [&](int pp, int t, int buf) {
+        dma16(vrsrc, lds_base + VBASE + buf * VTILE + (wave + 4 * pp) * 1024, vvo[pp] + t * 64 * vrs);
+    };
+    auto dma_k = [&](int u, int buf) {
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) dma_k1(pp, u, buf);
+    };
+    auto dma_v = [&](int t, int buf) {
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) dma_v1(pp, t, buf);
+    };
 
     const int kend = CAUSAL ? ((qi * BR + BR) < N ? (qi * BR + BR) : N) : N;
     const int nt = (kend + 63) >> 6;    // V tiles = loop iterations of this workgroup
@@ -142,42 +190,17 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
     int nb = nblk;                      // ... of this wave: up to the diagonal block of its second query block
     if (CAUSAL) nb = (q0 >> 5) + 2 < nblk ? (q0 >> 5) + 2 : nblk;
 
-    u32x4 kreg[CPT], vreg[CPT];
-    // tile offsets go into the VGPR offset (range-checked), never into soffset (unsigned, unchecked)
-    auto load_k = [&](int u) {
-        const int base = (u * 64 - 32) * krs + kvo;
+    int k_off[KS];  // K row read: row (half*32 + i), chunk 2ks + h
 #pragma unroll
-        for (int it = 0; it < CPT; ++it)
-            kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, base + it * RPI * krs, 0, 0));
-    };
-    auto load_v = [&](int t) {
-        const int base = t * 64 * vrs + vvo;
-#pragma unroll
-        for (int it = 0; it < CPT; ++it)
-            vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, base + it * RPI * vrs, 0, 0));
-    };
-    auto load_k1 = [&](int it, int u) {
-        kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, (u * 64 - 32 + it * RPI) * krs + kvo, 0, 0));
-    };
-    auto load_v1 = [&](int it, int t) {
-        vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, (t * 64 + it * RPI) * vrs + vvo, 0, 0));
-    };
-    auto write_k1 = [&](int it, int buf) { *(LDS_PTR(u32x4))(lds + buf * KUNIT + st_k + it * RPI * KROWB) = kreg[it]; };
-    auto write_v1 = [&](int it, int buf) { *(LDS_PTR(u32x4))(lds + buf * VTILE + st_v + it * RPI * VROWB) = vreg[it]; };
-    auto write_k = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < CPT; ++it) *(LDS_PTR(u32x4))(lds + buf * KUNIT + st_k + it * RPI * KROWB) = kreg[it];
-    };
-    auto write_v = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < CPT; ++it) *(LDS_PTR(u32x4))(lds + buf * VTILE + st_v + it * RPI * VROWB) = vreg[it];
-    };
-
-    const int kbase = i * KROWB + h * 16;
-    int vbase;
+    for (int ks = 0; ks < KS; ++ks) k_off[ks] = lds_off(i, 2 * ks + h);
+    int v_off[2][DB];  // V transposed read (fa2_mfma16.hip): u = keys +0..3 / +8..11 of the 16-key step
     {
         const int w = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
-        vbase = VBASE + (4 * h + qq) * VROWB + (2 * w + (pp >> 1)) * 16 + 8 * (pp & 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                v_off[u][db] = VBASE + lds_off(8 * u + 4 * h + qq, 4 * db + 2 * w + (pp >> 1)) + 8 * (pp & 1);
     }
 
     f32x16 o[QB][DB];
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
             for (int r = 0; r < 16; ++r) s[qb][r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const frag kf = __builtin_bit_cast(frag, *(LDS_PTR(u32x4))(lds + koff + kbase + ks * 32));
+            const frag kf = __builtin_bit_cast(frag, *(LDS_PTR(u32x4))(lds + koff + k_off[ks]));
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) s[qb] = M::mfma(kf, qf[qb][ks], s[qb]);
         }
@@ -291,9 +314,9 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const int off = voff + vbase + ss * 16 * VROWB + db * 64;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + 8 * VROWB));
+                const int off = voff + ss * 16 * VROWB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + v_off[0][db]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + v_off[1][db]));
                 const frag vf = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) o[qb][db] = M::mfma(vf, pf[qb][ss], o[qb][db]);
@@ -301,17 +324,12 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
     };
     auto block_masked = [&](int j) { return (CAUSAL && (j * 32 + 31 > q0)) || (j * 32 + 32 > N); };
 
-    // ---- prologue: K units 0..2 and V tile 0 in LDS; (K unit 3, V tile 1) in flight in the staging registers
-    load_k(0);
-    load_v(0);
-    write_k(0);
-    write_v(0);
-    load_k(1);
-    write_k(1);
-    load_k(2);
-    write_k(2);
-    load_k(3);
-    load_v(1);
+    // ---- prologue: K units 0..2 and V tile 0
+    dma_k(0, 0);
+    dma_v(0, 0);
+    dma_k(1, 1);
+    dma_k(2, 2);
+    dma_wait();
     __syncthreads();
 
     f32x16 sA[QB], sB[QB];
@@ -339,18 +357,18 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
     // Operand stream: ops 0..7 = K fragments, ops 8..15 = V fragments, ops 16, 17 = K fragments 0, 1 of the
     // FOLLOWING half; op n lives in ring[n & 3], step n consumes op n and issues the read of op n+2.
     auto lds_k = [&](int off) { return __builtin_bit_cast(frag, *(LDS_PTR(u32x4))(lds + off)); };
-    auto lds_v = [&](int off) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + 8 * VROWB));
+    auto lds_v = [&](int off, int db) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + v_off[0][db]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + off + v_off[1][db]));
         return __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto half_iter = [&](f32x16 (&sCur)[QB], f32x16 (&sNxt)[QB], frag (&ring)[4], int koff, int voff, int knext,
                          float (&coeff)[QB], auto &&staging) -> bool {
         auto issue = [&](int n) {  // n is a compile-time constant at every call site (unrolled loops)
             if constexpr (ABL & 4) return;
-            if (n < 8) ring[n & 3] = lds_k(koff + kbase + n * 32);
-            else if (n < 16) ring[n & 3] = lds_v(voff + vbase + ((n - 8) >> 2) * 16 * VROWB + ((n - 8) & 3) * 64);
-            else ring[n & 3] = lds_k(knext + kbase + (n - 16) * 32);
+            if (n < 8) ring[n & 3] = lds_k(koff + k_off[n & 7]);
+            else if (n < 16) ring[n & 3] = lds_v(voff + ((n - 8) >> 2) * 16 * VROWB, (n - 8) & 3);
+            else ring[n & 3] = lds_k(knext + k_off[(n - 16) & 7]);
         };
         constexpr int PD = 3;  // read-ahead distance in steps; the ring holds ops n .. n+PD
         float rs[QB] = {0.0f, 0.0f};
@@ -432,27 +450,20 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
     int t = 0, kb1 = 1, kb2 = 2, kb3 = 0;
     if (t_steady > 0) {
         frag ring[4];
-        ring[0] = lds_k(KUNIT + kbase);       // K fragments 0..2 of block 1 (rows 0..31 of K unit 1)
-        ring[1] = lds_k(KUNIT + kbase + 32);
-        ring[2] = lds_k(KUNIT + kbase + 64);
+        ring[0] = lds_k(KUNIT + k_off[0]);    // K fragments 0..2 of block 1 (rows 0..31 of K unit 1)
+        ring[1] = lds_k(KUNIT + k_off[1]);
+        ring[2] = lds_k(KUNIT + k_off[2]);
         for (; t < t_steady; ++t) {
             pin_q_agpr();
             const int kcur = kb1 * KUNIT;      // K unit t+1: rows 0..31 = block 2t+1, rows 32..63 = block 2t+2
             const int vcur = (t & 1) * VTILE;  // V tile t:   rows 0..31 = block 2t,   rows 32..63 = block 2t+1
             const int vwr = (t + 1) & 1;
-            // first half: the staging registers (K unit t+3, V tile t+1) go to LDS, one 16-byte chunk per step 0..7,
-            // and are refilled at once (steps 8..15) with the loads of (K unit t+4, V tile t+2): those have almost a
-            // whole iteration (~1 us) to land -- with the loads in the second half (~0.5 us ahead) the vmcnt wait in
-            // front of the next iteration's first LDS write stalled the SIMD's only wave (-19 %)
+            // first half: one DMA piece per even step -- K unit t+3 into the ring buffer released by the last barrier,
+            // V tile t+1 into the other V buffer; they land during this iteration and are published by its barrier
             auto stage_wr = [&](int n) {
-                if constexpr (ABL & 8) return;
-                if (n < 4) write_k1(n, kb3);
-                else if (n < 8) write_v1(n - 4, vwr);
-                else {
-                    if constexpr (ABL & 32) return;
-                    if (n < 12) load_k1(n - 8, t + 4);
-                    else load_v1(n - 12, t + 2);
-                }
+                if (n & 1) return;
+                if (n < 8) dma_k1(n >> 1, t + 3, kb3);
+                else dma_v1((n - 8) >> 1, t + 1, vwr);
             };
             auto stage_ld = [&](int) {};
             rescale(fireA, coeffA);
@@ -461,7 +472,8 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
             // ops 16, 17 of this half = K fragments 0, 1 of block 2t+3 = rows 0..31 of unit t+2 (published during
             // iteration t-1): the next iteration starts with its operands already in registers
             fireA = half_iter(sB, sA, ring, kcur + 32 * KROWB, vcur + 32 * VROWB, kb2 * KUNIT, coeffA, stage_ld);
-            if constexpr (!(ABL & (8 | 16))) __syncthreads();   // ABL 16: no barrier only
+            dma_wait();
+            __syncthreads();
             const int k0 = kb1;
             kb1 = kb2;
             kb2 = kb3;
@@ -471,10 +483,8 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
     for (; t < nt; ++t) {
         const bool more = t + 1 < nt;
         if (more) {
-            write_k(kb3);
-            write_v((t + 1) & 1);
-            load_k(t + 4);
-            load_v(t + 2);
+            dma_k(t + 3, kb3);
+            dma_v(t + 1, (t + 1) & 1);
         }
         const int kcur = kb1 * KUNIT;
         const int vcur = (t & 1) * VTILE;
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
             pv(pf, vcur + 32 * VROWB);
         }
         if (jA2 < nb) fireA = partial(sA, jA2, coeffA, block_masked(jA2));
+        dma_wait();
         __syncthreads();
         const int k0 = kb1;
         kb1 = kb2;
@@ -535,7 +546,7 @@ template <typename T, int ABL> int launch_t(const Fa2Problem &p, const XArgs &a)
         return FA2_ERR_BAD_ARG;
     }
     const dim3 grid((unsigned)nblk), block(256);
-    constexpr size_t smem = 3 * 64 * (128 * 2 + 16) + 2 * 64 * (128 * 2 + 64);
+    constexpr size_t smem = 5 * 64 * 256;  // three K units + two V tiles
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)fa2_fwd_mfma16x_kernel<T, true, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
