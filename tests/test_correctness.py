@@ -8,10 +8,13 @@ failure when run as a script, and the backward half is out of scope (SURVEY.md s
 
     python tests/test_correctness.py            # 200 seeds, prints the reference's summary line
 """
+import os
 import sys
 
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # runnable as a plain script
 
 B = 32
 H = 32

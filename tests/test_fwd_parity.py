@@ -178,6 +178,48 @@ def test_seeded_vs_oracle(oracle, dtype, causal, shape):
         check_L(L, L_ref, dtype)
 
 
+BIG_SHAPES = [(1, 3, 1000, 128), (2, 4, 777, 64), (1, 8, 1536, 128), (1, 16, 640, 128), (3, 8, 513, 64)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", BIG_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_ragged_multi_tile_shapes_vs_oracle(oracle, dtype, causal, shape):
+    """Several Q tiles per (b, h) with ragged N: odd and even tile counts (causal tile pairs with and without a
+    middle tile), B*H a multiple of 8 (XCD group mapping) and not, tails in both the Q and the K direction."""
+    Q, K, V = _rand(shape, dtype, seed=sum(shape) * 3 + int(causal))
+    O_ref, L_ref = _oracle(oracle, Q, K, V, dtype, causal)
+    variants = ["auto"] + (["mfma16d", "mfma16d_w4", "mfma16p_w8"] if dtype != torch.float32 else [])
+    for variant in variants:
+        O, L = hip_forward(Q, K, V, causal=causal, variant=variant)
+        if dtype == torch.float32:
+            assert torch.allclose(O_ref, O, atol=1e-4, rtol=1e-5), variant
+        assert (O.float() - O_ref).abs().max() <= O_TOL[dtype], variant
+        check_L(L, L_ref, dtype)
+
+
+def test_concurrent_streams_are_independent():
+    """The library is re-entrant and launches on the stream it is given: two problems on two streams at once."""
+    torch.manual_seed(5)
+    a = [torch.randn(2, 8, 1024, 128, device=DEV).bfloat16() for _ in range(3)]
+    b = [torch.randn(1, 8, 2048, 128, device=DEV).bfloat16() for _ in range(3)]
+    Oa, La = fa.flash_attention_forward(*a, DEV, causal=True)
+    Ob, Lb = fa.flash_attention_forward(*b, DEV, causal=False)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            o1 = fa.flash_attention_forward(*a, DEV, causal=True)
+        with torch.cuda.stream(s2):
+            o2 = fa.flash_attention_forward(*b, DEV, causal=False)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for (o1, o2) in outs:
+        assert torch.equal(o1[0], Oa) and torch.equal(o1[1], La)
+        assert torch.equal(o2[0], Ob) and torch.equal(o2[1], Lb)
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_fp64_generic(oracle, causal):
     Q, K, V = _rand((1, 2, 80, 32), torch.float64, seed=5)
