@@ -362,26 +362,41 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16d_kernel(const DmaAr
             __syncthreads();
         }
 
-        // ---- epilogue (kernels.py:105-108)
+        // ---- epilogue (kernels.py:105-108).  A lane owns one ROW of O (columns 32db + 8g + 4h ..+3): stored straight
+        // from the accumulators that is 16 eight-byte stores per lane, each instruction touching 32 rows.  Instead the
+        // wave's 32 x D tile goes through its own 32*ROWB-byte slice of the (now idle) K/V buffers and leaves as
+        // whole rows: ROWB/16 lanes x 16 bytes per row, 1 KiB contiguous per store instruction.
         const float l = half_swap_sum(lsum);
         const float inv = 1.0f / l;
-        if (qrow < N) {
-            char *op = a.O + (int64_t)b * a.os[0] + (int64_t)hh * a.os[1] + (int64_t)qrow * a.os[2] + h * 8;
-    #pragma unroll
+        {
+            const int ebase = wave * 32 * ROWB;  // NW * 32 * ROWB <= 4 * TILEB
+#pragma unroll
             for (int db = 0; db < DB; ++db)
-    #pragma unroll
+#pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     typedef __attribute__((ext_vector_type(4))) T Tx4;
                     Tx4 v;
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = (T)(o[db][4 * g + j] * inv);
-                    *(u32x2 *)(op + db * 64 + g * 16) = __builtin_bit_cast(u32x2, v);
+                    *(LDS_PTR(u32x2))(lds + ebase + lds_off<D>(i, 4 * db + g) + 8 * h) = __builtin_bit_cast(u32x2, v);
                 }
-            if (h == 0) {
-                T *lp = (T *)a.L + b * a.ls[0] + hh * a.ls[1] + qrow;
-                *lp = (T)(m + __builtin_amdgcn_logf(l));
+            // same wave wrote and reads: LDS executes a wave's accesses in order; no other wave touches this slice
+            // until the barrier below
+            constexpr int RPI = 64 / CPR;  // rows per store instruction (4 at d = 128, 8 at d = 64)
+            const int er = lane / CPR, ec = lane % CPR;
+            char *ob = a.O + (int64_t)b * a.os[0] + (int64_t)hh * a.os[1];
+#pragma unroll
+            for (int k = 0; k < 32 / RPI; ++k) {
+                const int r = k * RPI + er;
+                const u32x4 val = *(LDS_PTR(u32x4))(lds + ebase + lds_off<D>(r, ec));
+                if (q0 + r < N) *(u32x4 *)(ob + (int64_t)(q0 + r) * a.os[2] + ec * 16) = val;
             }
         }
+        if (qrow < N && h == 0) {
+            T *lp = (T *)a.L + b * a.ls[0] + hh * a.ls[1] + qrow;
+            *lp = (T)(m + __builtin_amdgcn_logf(l));
+        }
+        if (pass + 1 < npass) __syncthreads();  // the next pass's DMA reuses the slices
 
     }  // pass
 }

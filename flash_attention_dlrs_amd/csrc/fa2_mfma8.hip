@@ -368,24 +368,35 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8_kernel(const F8Args 
         }
 
         // ---- epilogue: O = O / l and L = m + log2 l, both rounded to fp8 (kernels.py:105-108).  Lane (i, h) owns
-        // row q0+i, columns 32db + 8g + 4h .. +3: four fp8 = one dword.
+        // row q0+i, columns 32db + 8g + 4h .. +3 (four fp8 = one dword); the wave's 32 x 128-byte tile goes through
+        // its own 4-KiB slice of the idle K/V buffers and leaves as whole rows (see fa2_mfma16d.hip).
         const float l = half_swap_sum(lsum);
         const float inv = 1.0f / l;
-        if (qrow < N) {
-            char *op = a.O + (int64_t)b * a.os[0] + (int64_t)hh * a.os[1] + (int64_t)qrow * a.os[2] + h * 4;
+        {
+            const int ebase = wave * 32 * ROWB;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int w = M::template cvt_pk<false>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv, 0);
                     w = M::template cvt_pk<true>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv, w);
-                    *(int *)(op + db * 32 + g * 8) = w;
+                    const int ch = 2 * db + (g >> 1);
+                    *(LDS_PTR(int))(lds + ebase + i * ROWB + ((ch ^ swz_k(i)) << 4) + 8 * (g & 1) + 4 * h) = w;
                 }
-            if (h == 0) {
-                const int w = M::template cvt_pk<false>(m + __builtin_amdgcn_logf(l), 0.0f, 0);
-                a.L[b * a.ls[0] + hh * a.ls[1] + qrow] = (char)(w & 0xff);
+            const int er = lane >> 3, ec = lane & 7;  // 8 rows x 8 chunks per store instruction
+            char *ob = a.O + (int64_t)b * a.os[0] + (int64_t)hh * a.os[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = k * 8 + er;
+                const u32x4 val = *(LDS_PTR(u32x4))(lds + ebase + r * ROWB + ((ec ^ swz_k(r)) << 4));
+                if (q0 + r < N) *(u32x4 *)(ob + (int64_t)(q0 + r) * a.os[2] + ec * 16) = val;
             }
         }
+        if (qrow < N && h == 0) {
+            const int w = M::template cvt_pk<false>(m + __builtin_amdgcn_logf(l), 0.0f, 0);
+            a.L[b * a.ls[0] + hh * a.ls[1] + qrow] = (char)(w & 0xff);
+        }
+        if (pass + 1 < npass) __syncthreads();  // the next pass's DMA reuses the slices
     }  // pass
 }
 
