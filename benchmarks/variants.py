@@ -23,7 +23,19 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    pairs = [p.split(":") for p in args.pairs.split(",")]
+    # pair = config:variant[:ENV=VALUE[+ENV=VALUE...]] -- the env settings are applied around that pair's launches
+    # (the library reads its tuning knobs per call)
+    triples = [(p.split(":") + [""])[:3] for p in args.pairs.split(",")]
+    envs = {f"{c}:{v}" + (f":{e}" if e else ""): dict(kv.split("=") for kv in e.split("+")) if e else {} for c, v, e in triples}
+    pairs = [(c, v + (f":{e}" if e else "")) for c, v, e in triples]
+
+    def launch(cfg, var, Q, K, V):
+        env = envs[f"{cfg}:{var}"]
+        for k, val in env.items():
+            os.environ[k] = val
+        flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var.split(":")[0])
+        for k in env:
+            os.environ.pop(k, None)
     data = {}
     for cfg, _ in pairs:
         if cfg not in data:
@@ -35,7 +47,7 @@ def main():
     for cfg, var in pairs:  # warm-up
         Q, K, V = data[cfg]
         for _ in range(3):
-            flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var)
+            launch(cfg, var, Q, K, V)
     torch.cuda.synchronize()
     for _ in range(args.rounds):
         for cfg, var in pairs:
@@ -43,7 +55,7 @@ def main():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(args.iters):
-                flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var)
+                launch(cfg, var, Q, K, V)
             b.record()
             torch.cuda.synchronize()
             res[f"{cfg}:{var}"].append(a.elapsed_time(b) / args.iters)

@@ -89,6 +89,8 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA8_W4: return fa2_launch_mfma8(p, 4);
     case FA2_VARIANT_MFMA16D: return fa2_launch_mfma16d(p, 8);
     case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
+    case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
+    case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
     case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
     case FA2_VARIANT_MFMA16X + 2048 * 3: return fa2_launch_mfma16x(p, 3);
     case FA2_VARIANT_MFMA16X + 2048 * 4: return fa2_launch_mfma16x(p, 4);
@@ -194,6 +196,8 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16D: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA16S: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA16S_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     default: out4[1] = 16; out4[2] = 64; out4[3] = 4; break;
     }

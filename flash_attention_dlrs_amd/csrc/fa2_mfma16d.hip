@@ -46,6 +46,7 @@ struct DmaArgs {
     int B, H, N;
     float c_log2e;
     int group;
+    int flags;  // experiment switches (FA2_FLAGS): 1 = static priority for waves 4..7
 };
 
 __device__ __forceinline__ void half_swap(float x, float &lo, float &hi) {
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16d_kernel(const DmaAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (M0, scalar branches)
     const int i = lane & 31, h = lane >> 5;
     const int N = a.N;
+    // T5 static form (cdna_hip_programming.md): the second-dispatched half loses VALU arbitration on every segment
+    if ((a.flags & 1) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
 
     // Causal: a workgroup owns the PAIR of Q tiles (nq-1-p, p) of one (b, h) and runs them back to back, heavy one
     // first -- every workgroup then does the same amount of work (nq+1 tile-steps), so the 256 CUs finish together
@@ -447,6 +450,7 @@ int fa2_launch_mfma16d(const Fa2Problem &p, int waves) {
     a.B = p.B; a.H = p.H; a.N = p.N;
     a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
     a.group = 1;
+    a.flags = fa2_env_int("FA2_FLAGS", 0);
     if (p.causal && ((p.B * p.H) & 7) == 0) {
         const int per_xcd = p.B * p.H / 8;
         int g = fa2_env_int("FA2_CAUSAL_GROUP", 2);

@@ -58,6 +58,8 @@ extern "C" {
 #define FA2_VARIANT_MFMA16D_W4 9 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA8 10  /* fp8 (e4m3fn / e5m2), d = 128, v_mfma_f32_32x32x16_fp8_fp8 / bf8_bf8; 8 waves    */
 #define FA2_VARIANT_MFMA8_W4 11 /* same, 4 waves x 32 rows                                            */
+#define FA2_VARIANT_MFMA16S 12 /* MFMA16D on v_mfma_f32_16x16x32 (d = 128): no lane exchange in the loop; 8 waves x 32 rows */
+#define FA2_VARIANT_MFMA16S_W4 13 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA16X 7 /* f16/bf16, d = 128: 4 waves x 64 rows, one wave per SIMD, every K/V    */
                               /* fragment read from LDS feeds two MFMAs                              */
 

@@ -44,7 +44,7 @@ def supported_variants(dtype, d):
     if dtype in (torch.float16, torch.bfloat16) and d in (64, 128):
         v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2", "mfma16d", "mfma16d_w4"]
         if d == 128:
-            v += ["mfma16x"]
+            v += ["mfma16x", "mfma16s", "mfma16s_w4"]
     if dtype == torch.float32 and d in (64, 128):
         v += ["mfma32"]
     return v
@@ -190,6 +190,8 @@ def test_ragged_multi_tile_shapes_vs_oracle(oracle, dtype, causal, shape):
     Q, K, V = _rand(shape, dtype, seed=sum(shape) * 3 + int(causal))
     O_ref, L_ref = _oracle(oracle, Q, K, V, dtype, causal)
     variants = ["auto"] + (["mfma16d", "mfma16d_w4", "mfma16p_w8"] if dtype != torch.float32 else [])
+    if dtype != torch.float32 and shape[-1] == 128:
+        variants += ["mfma16s", "mfma16s_w4"]
     for variant in variants:
         O, L = hip_forward(Q, K, V, causal=causal, variant=variant)
         if dtype == torch.float32:
@@ -278,7 +280,9 @@ def test_fp8_mfma_kernel(oracle, dtype, causal, variant, shape):
 
 
 @pytest.mark.parametrize("dtype,variant", [(torch.float32, "mfma32"), (torch.bfloat16, "mfma16"),
-                                           (torch.bfloat16, "mfma16_w8"), (torch.float32, "generic")])
+                                           (torch.bfloat16, "mfma16_w8"), (torch.float32, "generic"),
+                                           (torch.bfloat16, "mfma16d"), (torch.bfloat16, "mfma16s"),
+                                           (torch.float16, "mfma16s_w4")])
 def test_scale_extension(oracle, dtype, variant):
     Q, K, V = _rand((1, 2, 192, 128), dtype, seed=21)
     scale = 1.0 / math.sqrt(128)
@@ -289,7 +293,10 @@ def test_scale_extension(oracle, dtype, variant):
 
 
 @pytest.mark.parametrize("dtype,variant", [(torch.float32, "mfma32"), (torch.bfloat16, "mfma16"),
-                                           (torch.float16, "mfma16_w8"), (torch.float32, "generic")])
+                                           (torch.float16, "mfma16_w8"), (torch.float32, "generic"),
+                                           (torch.bfloat16, "mfma16d"), (torch.float16, "mfma16d"),
+                                           (torch.bfloat16, "mfma16s"), (torch.float16, "mfma16s"),
+                                           (torch.bfloat16, "mfma16s_w4")])
 def test_rescale_branch_is_exercised(oracle, dtype, variant):
     """Online-softmax rescaling: make the running max jump at LATE tiles (keys grow in norm and one
     spiked key sits in the last tile), so O *= coeff is taken with coeff << 1 after O is non-zero."""
@@ -306,9 +313,10 @@ def test_rescale_branch_is_exercised(oracle, dtype, variant):
 
 def test_no_out_of_bounds_writes_for_ragged_N():
     """O and L of a ragged problem sit inside a poisoned arena; nothing outside them may change."""
-    for dtype, variant in ((torch.float32, "mfma32"), (torch.bfloat16, "mfma16"), (torch.bfloat16, "mfma16_w8"),
-                           (torch.float32, "generic")):
-        B, H, N, d = 1, 2, 77, 64
+    for dtype, variant, d in ((torch.float32, "mfma32", 64), (torch.bfloat16, "mfma16", 64),
+                              (torch.bfloat16, "mfma16_w8", 64), (torch.float32, "generic", 64),
+                              (torch.bfloat16, "mfma16d", 128), (torch.bfloat16, "mfma16s", 128)):
+        B, H, N = 1, 2, 77
         Q, K, V = (t.to(DEV) for t in _rand((B, H, N, d), dtype, seed=3))
         arena = torch.full((3, B, H, N, d), 7.0, dtype=dtype, device=DEV)
         arena_l = torch.full((3, B, H, N, 1), 7.0, dtype=dtype, device=DEV)
