@@ -60,7 +60,8 @@ int pick_variant(const Fa2Problem &p) {
         // Software-pipelined kernel with LDS-DMA staging.  8 waves x 32 rows halves the K/V traffic per query
         // row; it needs enough 256-row tiles to fill 256 CUs, otherwise the 128-row tile spreads the work wider.
         // (N * row stride >= 2 GiB does not fit the 32-bit buffer offsets: fall back to the first MFMA kernel.)
-        const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31);
+        const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31) &&
+                            (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
         if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
         return wg256 >= 512 ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16D_W4;
@@ -89,6 +90,8 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA8_W4: return fa2_launch_mfma8(p, 4);
     case FA2_VARIANT_MFMA16D: return fa2_launch_mfma16d(p, 8);
     case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
+    case FA2_VARIANT_MFMA16H: return fa2_launch_mfma16h(p, 8);
+    case FA2_VARIANT_MFMA16H_W4: return fa2_launch_mfma16h(p, 4);
     case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
     case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
     case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
@@ -196,6 +199,8 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16D: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA16H: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA16H_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16S: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16S_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;

@@ -1,0 +1,682 @@
+// fa2_mfma16h.hip -- fa2_mfma16d.hip (f16 / bf16, 32-key blocks skewed by one block, LDS-DMA staging) with
+//   (1) a PERSISTENT grid: a workgroup walks its work units (causal: tile pairs) and sends the next job's first K/V
+//       tiles and Q rows on their way BEFORE the current job's epilogue, which has its own LDS slices;
+//   (2) a HAND-ORDERED steady loop: every MFMA is one fenced step (__builtin_amdgcn_sched_barrier(0)) that carries
+//       its share of the LDS reads and of the softmax arithmetic, K fragments of the next block are fetched under the
+//       P.V MFMAs of this one, and the loop is unrolled over the buffer parity so that every LDS address is a
+//       per-lane base register plus an immediate (no address arithmetic in the loop).
+// Arithmetic, layouts and the tail / causal-diagonal path are those of fa2_mfma16d.hip (variant "mfma16h").
+#include "fa2_common.h"
+
+#ifdef FA2_STAMPS
+// Diagnostic build only (make stamps): per-phase s_memtime sums of workgroup 0, [wave][slot]; slot 15 = trips.
+__device__ unsigned long long fa2_stamp_buf[8][16];
+extern "C" int fa2_debug_read_stamps(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fa2_stamp_buf), sizeof(fa2_stamp_buf));
+}
+#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T *
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<_Float16> {
+    using frag = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <int V> struct IC { static constexpr int value = V; };
+
+struct DmaArgs {
+    const char *Q, *K, *V;
+    char *O, *L;
+    int64_t qs[3], ks[3], vs[3], os[3];  // B, H, N strides in bytes
+    int64_t ls[2];
+    int B, H, N;
+    float c_log2e;
+    int group;
+    int flags;  // experiment switches (FA2_FLAGS): 1 = static priority for waves 4..7
+};
+
+__device__ __forceinline__ void half_swap(float x, float &lo, float &hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a = r[0], b = r[1];  // scalars first: bit_cast on a vector element reads element 0 (clang bug)
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float half_swap_max(float x) {
+    float lo, hi;
+    half_swap(x, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    float lo, hi;
+    half_swap(x, lo, hi);
+    return lo + hi;
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, per-lane byte offset) to LDS at lds_base + lane*16.
+// Inline asm ON PURPOSE: with the builtin, hipcc cannot tell the DMA's destination buffer from the buffer being
+// read and puts `s_waitcnt vmcnt(0)` in front of the first ds_read of the V tile -- the transfer then has a
+// quarter of an iteration to land instead of a whole one.  The compiler does not see these loads: the
+// `s_waitcnt vmcnt(0)` in front of the publishing barrier is ours (dma_wait()).  M0 is saved and restored.
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_base, int voffset) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(voffset), "s"(rsrc)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// chunk swizzle of a row inside a [64][D] 16-bit tile (function of row & 15 only)
+template <int D> __device__ __forceinline__ int swz(int row) {
+    if constexpr (D == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+    else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+}
+template <int D> __device__ __forceinline__ int lds_off(int row, int ch) { return row * (D * 2) + ((ch ^ swz<D>(row)) << 4); }
+
+// Raw-buffer stores for the epilogue: rows past N fall outside the descriptor and are dropped by the range check,
+// so every wave issues the SAME number of store instructions whatever N is -- the counted `s_waitcnt vmcnt(NST)`
+// of the job loop depends on that.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_store_rsrc(char *base, int bytes) {
+    const uint64_t ba = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)ba), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(ba >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <typename T, int D, int NW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaArgs a) {
+    using M = Mma<T>;
+    using frag = typename M::frag;
+    constexpr int BR = NW * 32;
+    constexpr int ROWB = D * 2, CPR = ROWB / 16;   // bytes per row, 16-byte chunks per row
+    constexpr int TILEB = 64 * ROWB;               // K unit = V tile = 64 rows
+    constexpr int RPP = 1024 / ROWB;               // rows per 1-KiB DMA piece (4 or 8)
+    constexpr int PIECES = TILEB / 1024, PPW = PIECES / NW;  // pieces per tile, per wave
+    constexpr int VBASE = 2 * TILEB;               // LDS: Kunit0 | Kunit1 | Vtile0 | Vtile1 [| epilogue slices]
+    constexpr int KS = D / 16, DB = D / 32;
+    // 8-wave build (one workgroup per CU): the epilogue has its OWN LDS slices, so the next job's first K/V tiles
+    // and Q rows are already in flight while this job's O leaves.  4-wave build (two workgroups per CU, LDS is the
+    // limit): the slices alias the K/V buffers and the next job's loads start after the epilogue.
+    constexpr bool EPI_SEP = NW == 8;
+#ifndef FA2_STAGGER
+#define FA2_STAGGER 0
+#endif
+    constexpr bool STAGGER = FA2_STAGGER != 0;
+    constexpr int EPI0 = EPI_SEP ? 4 * TILEB : 0;
+    constexpr int RPI = 64 / CPR;                  // rows per epilogue store instruction (4 at d = 128, 8 at d = 64)
+    constexpr int NST = 32 / RPI + 1;              // store instructions per wave and job: O rows + L
+    static_assert(PPW >= 1, "too many waves for this tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS_PTR(char) lds = (LDS_PTR(char))smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (M0, scalar branches)
+    const int i = lane & 31, h = lane >> 5;
+    const int N = a.N;
+    // T5 static form (cdna_hip_programming.md): the second-dispatched half loses VALU arbitration on every segment
+    if ((a.flags & 1) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+
+    // ---- jobs.  A job = one Q tile of one (b, h).  Work units: non-causal = one tile; causal = the PAIR of tiles
+    // (nq-1-p, p), heavy one first -- every unit is then the same amount of work (nq+1 tile-steps), so the CUs finish
+    // together, and the pair shares its K/V through L2.  The grid is PERSISTENT: workgroup w walks units
+    // w, w + gridDim.x, ...  (gridDim.x is a multiple of 8 whenever there are more units than CUs, so a workgroup's
+    // units all map to the same `unit index & 7` = one XCD under round-robin placement: speed only).
+    const int nq = (N + BR - 1) / BR, nbh = a.B * a.H;
+    const int nunit = CAUSAL ? (nq + 1) / 2 : nq;  // work units per (b, h)
+    const int total = nunit * nbh;
+    auto decode = [&](int id, int &bh, int &unit) __attribute__((always_inline)) {
+        if ((nbh & 7) == 0) {  // whole (b, h) groups per XCD (speed only)
+            const int slot = id >> 3, G = a.group;
+            const int batch = slot / (G * nunit), r = slot - batch * (G * nunit);
+            bh = (batch * G + r % G) * 8 + (id & 7);
+            unit = r / G;
+        } else {
+            bh = id / nunit;
+            unit = id % nunit;
+        }
+    };
+
+    frag qf[KS];
+
+    // ---- DMA staging.  Piece p of a tile = rows RPP*p .. RPP*p+RPP-1 = 1 KiB of LDS; wave w issues pieces
+    // w, w+NW, ...  Lane l fills LDS (row = RPP*p + l / CPR, slot = l % CPR) with global chunk slot ^ f(row).
+    const int krs = (int)a.ks[2], vrs = (int)a.vs[2];
+    // descriptors built from wave-uniform scalars: {base lo, base hi, bytes, flags}; raw buffer (stride 0)
+    auto make_rsrc = [&](const char *base, int bytes) __attribute__((always_inline)) {
+        const uint64_t ba = (uint64_t)base;
+        i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)ba);
+        r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(ba >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane(bytes);
+        r[3] = 0x00020000;
+        return r;
+    };
+    i32x4 krsrc, vrsrc;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+    int kvo[PPW], vvo[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int row = RPP * (wave + pp * NW) + lane / CPR, slot = lane % CPR;
+        const int chunk = slot ^ swz<D>(row);
+        kvo[pp] = row * krs + chunk * 16;
+        vvo[pp] = row * vrs + chunk * 16;
+    }
+    auto dma_k = [&](int u, int buf) __attribute__((always_inline)) {  // K unit u = keys 64u-32 .. 64u+31 -> LDS K buffer buf
+        const int base = (u * 64 - 32) * krs;  // in the VGPR offset: range-checked ("negative" rows wrap -> zero)
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) dma16(krsrc, lds_base + buf * TILEB + (wave + pp * NW) * 1024, kvo[pp] + base);
+    };
+    auto dma_v = [&](int t, int buf) __attribute__((always_inline)) {
+        const int base = t * 64 * vrs;
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+            dma16(vrsrc, lds_base + VBASE + buf * TILEB + (wave + pp * NW) * 1024, vvo[pp] + base);
+    };
+    // A job's first loads: K units 0, 1, V tile 0 by LDS-DMA and this lane's Q row into registers.
+    auto issue_job_loads = [&](int bh_, int qi_) __attribute__((always_inline)) {
+        const int b_ = bh_ / a.H, hh_ = bh_ - b_ * a.H;
+        krsrc = make_rsrc(a.K + (int64_t)b_ * a.ks[0] + (int64_t)hh_ * a.ks[1], (N - 1) * krs + ROWB);
+        vrsrc = make_rsrc(a.V + (int64_t)b_ * a.vs[0] + (int64_t)hh_ * a.vs[1], (N - 1) * vrs + ROWB);
+        dma_k(0, 0);
+        dma_v(0, 0);
+        dma_k(1, 1);
+        const int qrow_ = qi_ * BR + wave * 32 + i;
+        const int row = qrow_ < N ? qrow_ : N - 1;
+        const char *qp = a.Q + (int64_t)b_ * a.qs[0] + (int64_t)hh_ * a.qs[1] + (int64_t)row * a.qs[2] + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(frag, *(const u32x4 *)(qp + ks * 32));
+    };
+
+    int q0 = 0, qrow = 0, kend = 0, nt = 0, nblk = 0, nb = 0;  // set per job
+
+    // ---- per-lane swizzled read offsets
+    int k_off[KS];  // K row read: row (half*32 + i), chunk 2ks + h
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) k_off[ks] = lds_off<D>(i, 2 * ks + h);
+    int v_off[2][DB];  // V transposed read (see fa2_mfma16.hip): u = keys +0..3 / +8..11 of the 16-key step
+    {
+        const int w = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                v_off[u][db] = VBASE + lds_off<D>(8 * u + 4 * h + qq, 4 * db + 2 * w + (pp >> 1)) + 8 * (pp & 1);
+    }
+
+    f32x16 o[DB];
+    float m = -INFINITY, lsum = 0.0f;
+    const float c = a.c_log2e;
+    // Rescale threshold in log2 units: P may reach 2^kThr before the running max is raised.  bf16 P has the
+    // fp32 exponent range (24 leaves 2^24 * N far below fp32 overflow in l and O); f16 P must stay below 65504.
+    // On N(0,1) inputs at scale 1 (score sigma ~ 16 log2 units) a threshold of 8 still fired ~20 times per wave
+    // and 4096 keys -- each time the whole workgroup waits at the next barrier -- 24 makes it rare.
+    constexpr float kThr = sizeof(T) == 2 && __is_same(T, _Float16) ? 12.0f : 24.0f;
+
+    auto qk = [&](f32x16 &s, int koff) __attribute__((always_inline)) {  // koff = buffer base + half * 32 rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 kf = *(LDS_PTR(u32x4))(lds + koff + k_off[ks]);
+            s = M::mfma(__builtin_bit_cast(frag, kf), qf[ks], s);
+        }
+    };
+    auto partial = [&](f32x16 &s, int j, float &coeff, bool masked) __attribute__((always_inline)) -> bool {
+        if (masked) {
+            int lim = N - 1;
+            if (CAUSAL) lim = qrow < lim ? qrow : lim;
+            const int klim = lim - (j * 32 + 4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) > klim) s[r] = -INFINITY;
+        }
+        float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = half_swap_max(mx) * c;
+        const bool fire = !__all(mx - m <= kThr);  // deferred running max, see fa2_mfma16p.hip
+        coeff = 1.0f;
+        if (fire) {
+            const float m_new = fmaxf(m, mx);
+            coeff = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+        }
+        return fire;
+    };
+    auto finish = [&](f32x16 &s, frag (&pf)[2]) {
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -m));
+            rs += p;
+            pf[r >> 3][r & 7] = (T)p;
+        }
+        lsum += rs;
+    };
+    auto rescale = [&](bool fire, float coeff) __attribute__((always_inline)) {
+        if (fire) {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = o[db][r];
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(coeff));
+                    o[db][r] = x;
+                }
+            asm volatile("s_nop 7" ::: "memory");
+            lsum *= coeff;
+        }
+    };
+    auto pv = [&](frag (&pf)[2], int voff) {  // voff = buffer base + half * 32 rows
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int rowb = voff + ss * 16 * ROWB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[0][db]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[1][db]));
+                const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = M::mfma(__builtin_bit_cast(frag, vf), pf[ss], o[db]);
+            }
+    };
+    auto block_masked = [&](int j) __attribute__((always_inline)) { return (CAUSAL && (j * 32 + 31 > q0)) || (j * 32 + 32 > N); };
+
+#ifdef FA2_STAMPS
+    unsigned long long st_acc[16] = {0}, st_last = 0;
+#endif
+    // ---- the job loop
+    int idx = blockIdx.x;
+    if (idx >= total) return;
+    int bh, unit, pass = 0;
+    decode(idx, bh, unit);
+    int qi = CAUSAL ? nq - 1 - unit : unit;
+    issue_job_loads(bh, qi);
+    dma_wait();
+    for (;;) {
+        __syncthreads();  // the job's first K/V tiles are published (and the previous job's last reads are over)
+        q0 = qi * BR + wave * 32;
+        qrow = q0 + i;
+        kend = CAUSAL ? ((qi * BR + BR) < N ? (qi * BR + BR) : N) : N;
+        nt = (kend + 63) >> 6;    // V tiles (= loop iterations)
+        nblk = (kend + 31) >> 5;  // 32-key blocks of this tile
+        nb = nblk;                // ... of this wave (causal: up to its diagonal block)
+        if (CAUSAL) nb = (q0 >> 5) + 1 < nblk ? (q0 >> 5) + 1 : nblk;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+        m = -INFINITY;
+        lsum = 0.0f;
+
+        f32x16 sA, sB;
+        float coeffA = 1.0f, coeffB = 1.0f;
+        bool fireA = false, fireB = false;
+        frag pf[2];
+        qk(sA, 32 * ROWB);  // block 0 = rows 32..63 of K unit 0
+        fireA = partial(sA, 0, coeffA, block_masked(0));
+        __syncthreads();    // K unit 0 is overwritten by unit 2 in iteration 0
+
+        int jm = nb;
+        if (CAUSAL) jm = (q0 >> 5) < jm ? (q0 >> 5) : jm;
+        if ((N >> 5) < jm) jm = N >> 5;
+        int t_steady = (jm - 1) / 2;
+        t_steady = t_steady < 0 ? 0 : (t_steady > nt ? nt : t_steady);
+
+        // ---- hand-ordered steady state: two iterations (= both buffer parities) per trip, four block steps.
+        // A step = QK phase (KS fenced sub-steps: one MFMA of S_next = K_blk(j+1).Q^T, one V fragment fetch for this
+        // step's P.V, one K fragment fetch for the later half of this phase, and 16/KS elements of P_j = exp2(S_j*c-m))
+        // followed by the PV phase (KS fenced sub-steps: one MFMA of O^T += V^T.P^T, the first K fragments of the NEXT
+        // step where that block is already published, and a slice of the row maximum of S_next), then the decision.
+        constexpr int R = KS / 2;  // fragment rings: a register set is refilled right after the MFMA that read it
+        frag kf[R], vf[R];
+        auto read_k = [&](int imm, int ks) __attribute__((always_inline)) {
+            const u32x4 x = *(LDS_PTR(u32x4))(lds + imm + k_off[ks]);
+            return __builtin_bit_cast(frag, x);
+        };
+        auto read_v = [&](int imm, int idx) __attribute__((always_inline)) {  // idx = ss * DB + db
+            const int rowb = imm + (idx / DB) * 16 * ROWB, db = idx % DB;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[0][db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[1][db]));
+            const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(frag, v);
+        };
+        constexpr int EPK = 16 / KS, S0 = KS / 4;
+        float rs0 = 0.0f, rs1 = 0.0f;
+        // P_j = exp2(S_j * c - m) runs as a three-stage pipeline over the QK sub-steps -- F (fma) of element group
+        // g+1, E (exp2) of group g, A/C (row sum, cvt) of group g-1 -- so that no instruction sits next to its
+        // producer: measured with in-kernel stamps, the unpipelined order (fma, exp, add back to back) made this
+        // phase dependency-latency bound, 93 cycles per sub-step against ~50 of issue.
+        auto stageF = [&](f32x16 &sCur, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < EPK; ++e) sCur[g * EPK + e] = __builtin_fmaf(sCur[g * EPK + e], c, -m);
+        };
+        auto stageE = [&](f32x16 &sCur, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < EPK; ++e) sCur[g * EPK + e] = __builtin_amdgcn_exp2f(sCur[g * EPK + e]);
+        };
+        auto stageAC = [&](f32x16 &sCur, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < EPK; ++e) {
+                const int r = g * EPK + e;
+                if (e & 1) rs1 += sCur[r];
+                else rs0 += sCur[r];
+                pf[r >> 3][r & 7] = (T)sCur[r];
+            }
+        };
+        // QK phase of a block step: S_next = K_blk . Q^T (KS MFMAs) under P = exp2(S_cur * c - m); fetches the later K
+        // fragments and the first V fragments of this step's P.V.
+        auto qk_phase = [&](auto kimm_, auto vimm_, auto pref_in_, f32x16 &sCur, f32x16 &sNext, bool fireCur, float coeffCur) __attribute__((always_inline)) {
+            constexpr int KIMM = decltype(kimm_)::value, VIMM = decltype(vimm_)::value;
+            constexpr bool PREF_IN = decltype(pref_in_)::value;
+            rescale(fireCur, coeffCur);
+            if (!PREF_IN) {
+#pragma unroll
+                for (int ks = 0; ks < R; ++ks) kf[ks] = read_k(KIMM, ks);
+            }
+            rs0 = rs1 = 0.0f;
+            stageF(sCur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    sNext = M::mfma(kf[0], qf[0], z);
+                } else {
+                    sNext = M::mfma(kf[ks % R], qf[ks], sNext);
+                }
+                if (ks < R) kf[ks] = read_k(KIMM, ks + R);
+                else vf[ks - R] = read_v(VIMM, ks - R);
+                if (ks + 1 < KS) stageF(sCur, ks + 1);
+                stageE(sCur, ks);
+                if (ks >= 1) stageAC(sCur, ks - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // PV phase: O^T += V_blk^T . P^T (KS MFMAs, MFMA-paced) under the row maximum of S_next; carries the DMA pieces
+        // of iteration DMA_T (if >= 0) and the first K fragments of the next QK phase (if that block is published).
+        auto pv_phase = [&](auto vimm_, auto kpref_, const int DMA_T, const int v_dma_buf, f32x16 &sCur, f32x16 &sNext,
+                            bool &fireNext, float &coeffNext) __attribute__((always_inline)) {
+            constexpr int VIMM = decltype(vimm_)::value, KPREF = decltype(kpref_)::value;
+            constexpr bool PREF_OUT = KPREF >= 0;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int idx = 0; idx < KS; ++idx) {
+                if (idx == 0) {
+                    stageAC(sCur, KS - 1);
+                    lsum += rs0 + rs1;
+                }
+                o[idx % DB] = M::mfma(vf[idx % R], pf[idx / DB], o[idx % DB]);
+                if (idx < R) vf[idx] = read_v(VIMM, idx + R);
+                else if (PREF_OUT) kf[idx - R] = read_k(KPREF, idx - R);
+                if (DMA_T >= 0 && idx < 2 * PPW) {
+                    const int pp = idx % PPW;
+                    if (idx < PPW) dma16(krsrc, lds_base + (DMA_T & 1) * TILEB + (wave + pp * NW) * 1024, kvo[pp] + ((DMA_T + 2) * 64 - 32) * krs);
+                    else dma16(vrsrc, lds_base + VBASE + v_dma_buf * TILEB + (wave + pp * NW) * 1024, vvo[pp] + (DMA_T + 1) * 64 * vrs);
+                }
+                if (idx >= S0) {
+                    const int lo = 16 * (idx - S0) / (KS - S0), hi = 16 * (idx + 1 - S0) / (KS - S0);
+#pragma unroll
+                    for (int r = lo; r < hi; ++r) mx = fmaxf(mx, sNext[r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mx = half_swap_max(mx) * c;
+            fireNext = !__all(mx - m <= kThr);
+            coeffNext = 1.0f;
+            if (fireNext) {
+                const float m_new = fmaxf(m, mx);
+                coeffNext = __builtin_amdgcn_exp2f(m - m_new);
+                m = m_new;
+            }
+        };
+        // The two halves of the workgroup run the four phases of an iteration ONE PHASE APART (waves w and w + NW/2
+        // share a SIMD): group X does QK.PV.QK.PV, group Y does PV.QK.PV.QK with its first PV finishing the previous
+        // iteration's second block -- so a SIMD always pairs a VALU-bound QK phase with an MFMA-paced PV phase instead
+        // of running two of a kind against each other (in-kernel stamps: lockstep waves took the SUM of their phases).
+        const bool groupY = STAGGER && wave >= NW / 2;
+        auto iterX = [&](auto par_, int t) __attribute__((always_inline)) {  // par_ = t & 1
+            constexpr int PAR = decltype(par_)::value;
+            constexpr int KCUR = (PAR ^ 1) * TILEB;  // K unit t+1: rows 0..31 = block 2t+1, rows 32..63 = block 2t+2
+            constexpr int VCUR = PAR * TILEB;        // V tile t:   rows 0..31 = block 2t,   rows 32..63 = block 2t+1
+            qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<0>{}, sA, sB, fireA, coeffA);
+            pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, t, PAR ^ 1, sA, sB, fireB, coeffB);
+            qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, sB, sA, fireB, coeffB);
+            pv_phase(IC<VCUR + 32 * ROWB>{}, IC<-1>{}, -1, 0, sB, sA, fireA, coeffA);
+            dma_wait();  // this wave's pieces of (K unit t+2, V tile t+1) have landed; the barrier publishes them
+            __syncthreads();
+        };
+        auto iterY = [&](auto par_, auto first_, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_)::value;
+            constexpr int KCUR = (PAR ^ 1) * TILEB, VCUR = PAR * TILEB, VPREV = (PAR ^ 1) * TILEB;
+            if (decltype(first_)::value) {
+                dma_k(t + 2, PAR);
+                dma_v(t + 1, PAR ^ 1);
+            } else {
+                pv_phase(IC<VPREV + 32 * ROWB>{}, IC<KCUR>{}, t, PAR ^ 1, sB, sA, fireA, coeffA);
+            }
+            qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<1>{}, sA, sB, fireA, coeffA);
+            pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, -1, 0, sA, sB, fireB, coeffB);
+            qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, sB, sA, fireB, coeffB);
+            dma_wait();
+            __syncthreads();
+        };
+        int t = 0;
+        if (!groupY) {
+            for (; t + 1 < t_steady; t += 2) {
+                iterX(IC<0>{}, t);
+                iterX(IC<1>{}, t + 1);
+            }
+        } else if (t_steady >= 2) {
+#pragma unroll
+            for (int ks = 0; ks < R; ++ks) kf[ks] = read_k(TILEB, ks);  // K unit 1 rows 0..31 (iteration 0's first block)
+            iterY(IC<0>{}, IC<1>{}, 0);
+            iterY(IC<1>{}, IC<0>{}, 1);
+            for (t = 2; t + 1 < t_steady; t += 2) {
+                iterY(IC<0>{}, IC<0>{}, t);
+                iterY(IC<1>{}, IC<0>{}, t + 1);
+            }
+            // group Y's deferred P.V of the last steady block
+            pv_phase(IC<TILEB + 32 * ROWB>{}, IC<-1>{}, -1, 0, sB, sA, fireA, coeffA);
+        }
+        for (; t < nt; ++t) {
+            const bool more = t + 1 < nt;
+            if (more) {
+                dma_k(t + 2, t & 1);
+                dma_v(t + 1, (t + 1) & 1);
+            }
+            const int kcur = ((t + 1) & 1) * TILEB;
+            const int vcur = (t & 1) * TILEB;
+            const int jA = 2 * t, jB = 2 * t + 1, jA2 = 2 * t + 2;
+            if (jA < nb) rescale(fireA, coeffA);
+            if (jB < nb) qk(sB, kcur);
+            if (jA < nb) {
+                finish(sA, pf);
+                pv(pf, vcur);
+            }
+            if (jB < nb) {
+                fireB = partial(sB, jB, coeffB, block_masked(jB));
+                rescale(fireB, coeffB);
+            }
+            if (jA2 < nb) qk(sA, kcur + 32 * ROWB);
+            if (jB < nb) {
+                finish(sB, pf);
+                pv(pf, vcur + 32 * ROWB);
+            }
+            if (jA2 < nb) fireA = partial(sA, jA2, coeffA, block_masked(jA2));
+            dma_wait();
+            __syncthreads();
+        }
+
+        // ---- this job's output addressing, then the NEXT job (its loads go out before the epilogue below)
+        const int b = bh / a.H, hh = bh - b * a.H;
+        const __amdgpu_buffer_rsrc_t orsrc =
+            make_store_rsrc(a.O + (int64_t)b * a.os[0] + (int64_t)hh * a.os[1], (int)((N - 1) * a.os[2]) + ROWB);
+        const __amdgpu_buffer_rsrc_t lrsrc =
+            make_store_rsrc(a.L + ((int64_t)b * a.ls[0] + (int64_t)hh * a.ls[1]) * (int64_t)sizeof(T), N * (int)sizeof(T));
+        const int eq0 = q0, eqrow = qrow;
+        bool has_next = true;
+        if (CAUSAL && pass == 0 && unit != nq - 1 - unit) {
+            pass = 1;
+            qi = unit;
+        } else {
+            idx += gridDim.x;
+            has_next = idx < total;
+            if (has_next) {
+                decode(idx, bh, unit);
+                qi = CAUSAL ? nq - 1 - unit : unit;
+                pass = 0;
+            }
+        }
+        if (EPI_SEP && has_next) issue_job_loads(bh, qi);
+
+        // ---- epilogue (kernels.py:105-108).  A lane owns one ROW of O (columns 32db + 8g + 4h ..+3): stored straight
+        // from the accumulators that is 16 eight-byte stores per lane, each instruction touching 32 rows.  Instead the
+        // wave's 32 x D tile goes through its own 32*ROWB-byte LDS slice and leaves as whole rows: ROWB/16 lanes x
+        // 16 bytes per row, 1 KiB contiguous per store instruction.
+        const float l = half_swap_sum(lsum);
+        const float inv = 1.0f / l;
+        {
+            const int ebase = EPI0 + wave * 32 * ROWB;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef __attribute__((ext_vector_type(4))) T Tx4;
+                    Tx4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (T)(o[db][4 * g + j] * inv);
+                    *(LDS_PTR(u32x2))(lds + ebase + lds_off<D>(i, 4 * db + g) + 8 * h) = __builtin_bit_cast(u32x2, v);
+                }
+            // same wave wrote and reads: LDS executes a wave's accesses in order; no other wave touches this slice
+            const int er = lane / CPR, ec = lane % CPR;
+#pragma unroll
+            for (int k = 0; k < 32 / RPI; ++k) {
+                const int r = k * RPI + er;
+                const u32x4 val = *(LDS_PTR(u32x4))(lds + ebase + lds_off<D>(r, ec));
+                __builtin_amdgcn_raw_buffer_store_b128(val, orsrc, (eq0 + r) * (int)a.os[2] + ec * 16, 0, 0);
+            }
+        }
+        {
+            const T lv = (T)(m + __builtin_amdgcn_logf(l));
+            const int loff = h == 0 ? eqrow * (int)sizeof(T) : 0x7ffffff0;  // upper half: out of range -> dropped
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lv), lrsrc, loff, 0, 0);
+        }
+#ifdef FA2_STAMPS
+        if (!has_next && blockIdx.x == 0 && lane == 0)
+            for (int k = 0; k < 16; ++k) fa2_stamp_buf[wave][k] = st_acc[k];
+#endif
+        if (!has_next) break;
+        if (EPI_SEP) {
+            // everything but this job's NST stores (the youngest) has completed: the next job's DMA pieces and Q rows
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        } else {
+            __syncthreads();  // the slices alias the K/V buffers
+            issue_job_loads(bh, qi);
+            dma_wait();
+        }
+    }
+}
+
+template <typename T, int D, int NW> int launch_t(const Fa2Problem &p, const DmaArgs &a) {
+    constexpr int BR = NW * 32;
+    const int nq = (p.N + BR - 1) / BR;
+    const long long nunits = (long long)(p.causal ? (nq + 1) / 2 : nq) * p.B * p.H;  // causal: one unit per tile pair
+    if (nunits > 0x7fffffffLL) {
+        fa2_set_error("mfma16h: too many work units");
+        return FA2_ERR_BAD_ARG;
+    }
+    // persistent grid: one workgroup per CU (8 waves) or two (4 waves), a multiple of 8 (XCD affinity of the units)
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    long long slots = (long long)cus * (NW == 8 ? 1 : 2) * fa2_env_int("FA2_WG_PER_SLOT", 1);
+    slots -= slots % 8;
+    if (slots < 8) slots = 8;
+    const dim3 grid((unsigned)(nunits < slots ? nunits : slots)), block(NW * 64);
+    constexpr size_t smem = 4 * 64 * D * 2 + (NW == 8 ? NW * 32 * D * 2 : 0);  // K/V ring (+ epilogue slices)
+    auto launch = [&](auto kern) __attribute__((always_inline)) {
+        static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, smem, p.stream, a);
+    };
+    if (p.causal)
+        launch(fa2_fwd_mfma16h_kernel<T, D, NW, true>);
+    else
+        launch(fa2_fwd_mfma16h_kernel<T, D, NW, false>);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fa2_set_error("mfma16h kernel launch failed: %s", hipGetErrorString(e));
+        return FA2_ERR_LAUNCH;
+    }
+    return FA2_OK;
+}
+
+template <typename T> int launch_d(const Fa2Problem &p, const DmaArgs &a, int waves) {
+    if (p.d == 128) return waves == 8 ? launch_t<T, 128, 8>(p, a) : launch_t<T, 128, 4>(p, a);
+    return waves == 8 ? launch_t<T, 64, 8>(p, a) : launch_t<T, 64, 4>(p, a);
+}
+
+}  // namespace
+
+int fa2_launch_mfma16h(const Fa2Problem &p, int waves) {
+    const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31) &&
+                        (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
+    if (!fa2_mfma16_supports(p) || !fits32) {
+        fa2_set_error("mfma16h kernel: needs f16/bf16, d in {64,128}, unit d-stride, 16-byte aligned rows, scale > 0, "
+                      "N * row stride < 2 GiB");
+        return FA2_ERR_UNSUPPORTED;
+    }
+    DmaArgs a;
+    a.Q = (const char *)p.Q; a.K = (const char *)p.K; a.V = (const char *)p.V;
+    a.O = (char *)p.O; a.L = (char *)p.L;
+    for (int k = 0; k < 3; ++k) {
+        a.qs[k] = p.qs[k] * 2; a.ks[k] = p.ks[k] * 2; a.vs[k] = p.vs[k] * 2; a.os[k] = p.os[k] * 2;
+    }
+    a.ls[0] = p.ls[0]; a.ls[1] = p.ls[1];
+    a.B = p.B; a.H = p.H; a.N = p.N;
+    a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
+    a.group = 1;
+    a.flags = fa2_env_int("FA2_FLAGS", 0);
+    if (p.causal && ((p.B * p.H) & 7) == 0) {
+        const int per_xcd = p.B * p.H / 8;
+        int g = fa2_env_int("FA2_CAUSAL_GROUP", 2);
+        g = g < 1 ? 1 : (g > per_xcd ? per_xcd : g);
+        while (per_xcd % g) --g;
+        a.group = g;
+    }
+    return p.dtype == FA2_DTYPE_BF16 ? launch_d<__bf16>(p, a, waves) : launch_d<_Float16>(p, a, waves);
+}

@@ -42,7 +42,7 @@ def hip_forward(Q, K, V, causal=False, scale=1.0, variant="auto"):
 def supported_variants(dtype, d):
     v = ["auto", "generic"]
     if dtype in (torch.float16, torch.bfloat16) and d in (64, 128):
-        v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2", "mfma16d", "mfma16d_w4"]
+        v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2", "mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4"]
         if d == 128:
             v += ["mfma16x", "mfma16s", "mfma16s_w4"]
     if dtype == torch.float32 and d in (64, 128):
@@ -189,7 +189,7 @@ def test_ragged_multi_tile_shapes_vs_oracle(oracle, dtype, causal, shape):
     middle tile), B*H a multiple of 8 (XCD group mapping) and not, tails in both the Q and the K direction."""
     Q, K, V = _rand(shape, dtype, seed=sum(shape) * 3 + int(causal))
     O_ref, L_ref = _oracle(oracle, Q, K, V, dtype, causal)
-    variants = ["auto"] + (["mfma16d", "mfma16d_w4", "mfma16p_w8"] if dtype != torch.float32 else [])
+    variants = ["auto"] + (["mfma16d", "mfma16d_w4", "mfma16p_w8", "mfma16h", "mfma16h_w4"] if dtype != torch.float32 else [])
     if dtype != torch.float32 and shape[-1] == 128:
         variants += ["mfma16s", "mfma16s_w4"]
     for variant in variants:
@@ -296,7 +296,8 @@ def test_scale_extension(oracle, dtype, variant):
                                            (torch.float16, "mfma16_w8"), (torch.float32, "generic"),
                                            (torch.bfloat16, "mfma16d"), (torch.float16, "mfma16d"),
                                            (torch.bfloat16, "mfma16s"), (torch.float16, "mfma16s"),
-                                           (torch.bfloat16, "mfma16s_w4")])
+                                           (torch.bfloat16, "mfma16s_w4"), (torch.bfloat16, "mfma16h"),
+                                           (torch.float16, "mfma16h"), (torch.bfloat16, "mfma16h_w4")])
 def test_rescale_branch_is_exercised(oracle, dtype, variant):
     """Online-softmax rescaling: make the running max jump at LATE tiles (keys grow in norm and one
     spiked key sits in the last tile), so O *= coeff is taken with coeff << 1 after O is non-zero."""
@@ -315,7 +316,8 @@ def test_no_out_of_bounds_writes_for_ragged_N():
     """O and L of a ragged problem sit inside a poisoned arena; nothing outside them may change."""
     for dtype, variant, d in ((torch.float32, "mfma32", 64), (torch.bfloat16, "mfma16", 64),
                               (torch.bfloat16, "mfma16_w8", 64), (torch.float32, "generic", 64),
-                              (torch.bfloat16, "mfma16d", 128), (torch.bfloat16, "mfma16s", 128)):
+                              (torch.bfloat16, "mfma16d", 128), (torch.bfloat16, "mfma16s", 128),
+                              (torch.bfloat16, "mfma16h", 128), (torch.float16, "mfma16h_w4", 64)):
         B, H, N = 1, 2, 77
         Q, K, V = (t.to(DEV) for t in _rand((B, H, N, d), dtype, seed=3))
         arena = torch.full((3, B, H, N, d), 7.0, dtype=dtype, device=DEV)
