@@ -34,6 +34,9 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_
 
 # Every symbol include/fa2_fwd.h declares (tests/test_abi.py checks the export list against the header).
 SYMBOLS = ("fa2_fwd", "fa2_fwd_variant", "fa2_query_tile", "fa2_version", "fa2_last_error")
+# ... and include/fa2_bwd.h
+BWD_SYMBOLS = ("fa2_bwd", "fa2_bwd_variant")
+BWD_VARIANTS = {"auto": 0, "generic": 1, "mfma16": 2}
 
 _lib = None
 
@@ -60,6 +63,11 @@ def lib():
         l.fa2_fwd_variant.argtypes = common + [ctypes.c_int32]
         l.fa2_query_tile.restype = ctypes.c_int
         l.fa2_query_tile.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
+        bwd = [vp] * 10 + [i64p] * 9 + [ctypes.c_int32] * 6 + [ctypes.c_float, vp]
+        l.fa2_bwd.restype = ctypes.c_int
+        l.fa2_bwd.argtypes = bwd
+        l.fa2_bwd_variant.restype = ctypes.c_int
+        l.fa2_bwd_variant.argtypes = bwd + [ctypes.c_int32]
         l.fa2_version.restype = ctypes.c_char_p
         l.fa2_last_error.restype = ctypes.c_char_p
         _lib = l
@@ -104,6 +112,26 @@ def fa2_fwd(Q, K, V, O, L, dtype_enum, causal=False, scale=1.0, variant=VARIANT_
         rc = lib().fa2_fwd_variant(
             Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
             _i64(Q.stride()), _i64(K.stride()), _i64(V.stride()), _i64(O.stride()), _i64((LB, LH)),
+            B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), stream, int(variant))
+    if rc != 0:
+        _raise(rc)
+
+
+def fa2_bwd(Q, K, V, O, dO, L, dQ, dK, dV, D, dtype_enum, causal=False, scale=1.0, variant=0):
+    """Launch the backward (include/fa2_bwd.h) on the current stream of Q's device: the counterpart of the
+    reference's bwd_D_kernel + bwd_kernel launches (torch.py:124-155).  All buffers, the float32 scratch D
+    (2, B, H, N, 1) included, are allocated by the caller as the reference's glue does (torch.py:101-105)."""
+    if Q.device.type != "cuda":
+        raise NotImplementedError("Q, K, V must be on the same CUDA device")
+    B, H, N, d = Q.shape
+    assert D.is_contiguous() and D.numel() == 2 * B * H * N
+    with torch.cuda.device(Q.device):
+        stream = torch.cuda.current_stream(Q.device).cuda_stream
+        rc = lib().fa2_bwd_variant(
+            Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr(),
+            dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), D.data_ptr(),
+            _i64(Q.stride()), _i64(K.stride()), _i64(V.stride()), _i64(O.stride()), _i64(dO.stride()),
+            _i64(dQ.stride()), _i64(dK.stride()), _i64(dV.stride()), _i64((L.stride(0), L.stride(1))),
             B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), stream, int(variant))
     if rc != 0:
         _raise(rc)

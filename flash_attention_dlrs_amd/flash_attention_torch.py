@@ -7,9 +7,10 @@ The forward launches the hand-written gfx950 kernel through the C ABI (include/f
 of Triton.  `causal` and `scale` are optional extra positional arguments of `.apply` with
 reference-preserving defaults (no mask, scale 1).
 
-The backward is OUT OF the hot-path scope: it is provided so that
-`.backward()` works, as a device-side torch recompute from the saved log-sum-exp L -- not a native
-kernel (the reference's own backward kernels are documented as unreliable, README.md:45-53).
+The backward launches the hand-written gfx950 backward kernels through
+include/fa2_bwd.h: D = rowsum(dO * O), then a key-block-owner kernel for dK / dV and a query-block-owner kernel
+for dQ -- no cross-workgroup sum, hence deterministic, so FlashAttention and FlashAttentionDeterministic share
+it (the reference's two classes differ only in how they serialise the dQ sum, torch.py:86-158 vs :226-294).
 """
 import math
 
@@ -93,7 +94,8 @@ def _forward_impl(ctx, Q, K, V, causal, scale):
 
 
 def attention_backward_recompute(Q, K, V, O, dO, L, causal=False, scale=1.0):
-    """dQ, dK, dV from the saved statistics, in torch ops on the tensors' device (NOT a native kernel).
+    """dQ, dK, dV from the saved statistics in plain torch ops: a readable restatement used by the tests only
+    (the product path is _backward_native below).
     P = exp2(scale * S * log2e - L) (reference kernels.py:283-285), D = rowsum(dO * O) (kernels.py:120-166)."""
     f = torch.float64 if Q.dtype == torch.float64 else torch.float32
     q, k, v, o, do, l = (t.to(f) for t in (Q, K, V, O, dO, L))
@@ -112,13 +114,30 @@ def attention_backward_recompute(Q, K, V, O, dO, L, causal=False, scale=1.0):
     return dQ.to(Q.dtype), dK.to(K.dtype), dV.to(V.dtype)
 
 
+def backward_native(Q, K, V, O, dO, L, causal=False, scale=1.0, variant="auto"):
+    """Host glue of the backward launch (reference torch.py:101-155): allocate dQ, dK, dV (strides of Q, K, V) and
+    the scratch D, launch, return the gradients.  Inputs are already padded to a supported d."""
+    dtype = convert_triton_dtype(Q.dtype)
+    if Q.dtype in (torch.float8_e5m2, torch.float8_e4m3fn):
+        raise TypeError(f"dtype {Q.dtype} not supported by the backward.")
+    B, H, N, d = Q.shape
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    # scratch: rowsum(dO * O) and the fp32 row statistic handed from the dQ launch to the dK/dV launch (fa2_bwd.h)
+    D = torch.empty(2, B, H, N, 1, dtype=torch.float64 if Q.dtype == torch.float64 else torch.float32, device=Q.device)
+    if dO.stride(-1) != 1:
+        dO = dO.contiguous()
+    _lib.fa2_bwd(Q, K, V, O, dO, L, dQ, dK, dV, D, dtype, causal=causal, scale=scale,
+                 variant=_lib.BWD_VARIANTS[variant])
+    return dQ, dK, dV
+
+
 def _backward_impl(ctx, dO):
     Q, K, V, O, L = ctx.saved_tensors
     if Q.dtype != dO.dtype:
         raise ValueError("dO must have same dtype as inputs")
     if ctx.padded:
         dO = pad_last_dim(dO, ctx.d_used)
-    dQ, dK, dV = attention_backward_recompute(Q, K, V, O, dO, L, ctx.causal, ctx.scale)
+    dQ, dK, dV = backward_native(Q, K, V, O, dO, L, ctx.causal, ctx.scale)
     if ctx.padded:
         d = ctx.d_orig
         return dQ[..., :d], dK[..., :d], dV[..., :d], None, None

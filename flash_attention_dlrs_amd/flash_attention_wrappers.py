@@ -6,8 +6,8 @@ script (src/test_correctness.py:34) and the only place the log2-domain log-sum-e
 import torch
 
 from . import _lib
-from .flash_attention_torch import (MIN_TENSOR_SIZE, attention_backward_recompute, convert_triton_dtype,
-                                    next_power_of_2, pad_last_dim)
+from .flash_attention_torch import (MIN_TENSOR_SIZE, backward_native, convert_triton_dtype, next_power_of_2,
+                                    pad_last_dim)
 
 
 def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="auto"):
@@ -35,9 +35,17 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
     return O[:, :, :, 0:d], L
 
 
-def flash_attention_backward(Q, K, V, O, dO, L, dev, deterministic=False, *, causal=False, scale=1.0):
-    """(dQ, dK, dV).  Out of the hot-path scope: a torch recompute on
-    `dev`, not a native kernel; `deterministic` is accepted for signature parity (wrappers.py:66-75)."""
+def flash_attention_backward(Q, K, V, O, dO, L, dev, deterministic=False, *, causal=False, scale=1.0, variant="auto"):
+    """(dQ, dK, dV) through the native backward kernels (include/fa2_bwd.h).  Same signature as the reference
+    (wrappers.py:66-75); `deterministic` selects between two kernels there -- here the one implementation is
+    deterministic by construction, so the flag is accepted and ignored.  d is padded like in the forward
+    (wrappers.py:91-104) and the gradients are returned as [:d] views."""
     assert Q.dim() == 4
     assert Q.shape == K.shape and K.shape == V.shape and O.shape == Q.shape and dO.shape == Q.shape
-    return attention_backward_recompute(Q, K, V, O, dO, L, causal=causal, scale=scale)
+    assert Q.dtype == K.dtype and K.dtype == V.dtype and Q.dtype == dO.dtype
+    d = Q.shape[-1]
+    d_pow = max(next_power_of_2(d), MIN_TENSOR_SIZE)
+    if d_pow != d:
+        Q, K, V, O, dO = (pad_last_dim(t, d_pow) for t in (Q, K, V, O, dO))
+    dQ, dK, dV = backward_native(Q, K, V, O, dO, L, causal=causal, scale=scale, variant=variant)
+    return dQ[..., :d], dK[..., :d], dV[..., :d]

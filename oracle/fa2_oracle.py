@@ -25,8 +25,8 @@ _lib = None
 
 def build(force=False):
     """Compile fa2_oracle.c with gcc (seconds)."""
-    src = os.path.join(_HERE, "fa2_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("fa2_oracle.c", "fa2_oracle_bwd.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libfa2_oracle.so"])
     return _SO
 
@@ -45,6 +45,10 @@ def lib():
         _lib.fa2_oracle_fwd_f64.restype = ctypes.c_int
         _lib.fa2_oracle_fwd_f64.argtypes = [dp, dp, dp, dp, dp, i64p, i64p, i64p, i64p, i64p] + \
             [ctypes.c_int] * 5 + [ctypes.c_double]
+        _lib.fa2_oracle_bwd_D.restype = ctypes.c_int
+        _lib.fa2_oracle_bwd_D.argtypes = [fp, fp, fp] + [ctypes.c_int] * 5
+        _lib.fa2_oracle_bwd.restype = ctypes.c_int
+        _lib.fa2_oracle_bwd.argtypes = [fp] * 9 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
         _lib.fa2_oracle_round.restype = ctypes.c_float
         _lib.fa2_oracle_round.argtypes = [ctypes.c_float, ctypes.c_int]
     return _lib
@@ -83,6 +87,43 @@ def forward(Q, K, V, dtype="float32", causal=False, scale=1.0, B_r=16, B_c=16):
     if rc != 0:
         raise ValueError(f"fa2_oracle_fwd rc={rc} (N={N} must be a multiple of B_r={B_r}, B_c={B_c})")
     return O, L
+
+
+def backward(Q, K, V, O, dO, L, dtype="float32", causal=False, scale=1.0, B_r=16, B_c=16):
+    """The C restatement of the reference's bwd_D_kernel + bwd_kernel (fa2_oracle_bwd.c; kernels.py:115-334).
+    Inputs hold values already rounded to `dtype`; L is the forward's log2-domain LSE, shape (B, H, N[, 1]).
+    Returns (dQ, dK, dV, D) as float32 arrays whose values are rounded to `dtype` as the reference stores them."""
+    dt = DTYPE_NAMES[dtype] if isinstance(dtype, str) else int(dtype)
+    B, H, N, d = Q.shape
+    c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    Q, K, V, O, dO = (c(x) for x in (Q, K, V, O, dO))
+    L = c(np.asarray(L).reshape(B, H, N))
+    dQ, dK, dV = (np.empty((B, H, N, d), np.float32) for _ in range(3))
+    D = np.empty((B, H, N), np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    l = lib()
+    l.fa2_oracle_bwd_D(p(O), p(dO), p(D), B, H, N, d, dt)
+    rc = l.fa2_oracle_bwd(p(Q), p(K), p(V), p(dO), p(L), p(D), p(dQ), p(dK), p(dV), B, H, N, d, dt,
+                          int(bool(causal)), float(scale), min(B_r, N), min(B_c, N))
+    if rc != 0:
+        raise ValueError(f"fa2_oracle_bwd rc={rc} (N={N} must be a multiple of B_r={B_r}, B_c={B_c})")
+    return dQ, dK, dV, D
+
+
+def grads_f64(Q, K, V, dO, causal=False, scale=1.0):
+    """Independent fp64 numpy restatement of the gradients of softmax(scale * Q K^T [+ mask]) V."""
+    Q, K, V, dO = (np.asarray(x, dtype=np.float64) for x in (Q, K, V, dO))
+    S = np.einsum("bhnd,bhmd->bhnm", Q, K) * scale
+    if causal:
+        N = Q.shape[2]
+        S = np.where(np.tril(np.ones((N, N), bool)), S, -np.inf)
+    P = np.exp(S - S.max(axis=-1, keepdims=True))
+    P /= P.sum(axis=-1, keepdims=True)
+    dV = np.einsum("bhnm,bhnd->bhmd", P, dO)
+    dP = np.einsum("bhnd,bhmd->bhnm", dO, V)
+    D = (P * dP).sum(axis=-1, keepdims=True)
+    dS = P * (dP - D) * scale
+    return np.einsum("bhnm,bhmd->bhnd", dS, K), np.einsum("bhnm,bhnd->bhmd", dS, Q), dV
 
 
 def round_scalar(x, dtype):

@@ -12,16 +12,22 @@ from conftest import ROOT
 from flash_attention_dlrs_amd import _lib
 
 HEADER = os.path.join(ROOT, "include", "fa2_fwd.h")
+HEADER_BWD = os.path.join(ROOT, "include", "fa2_bwd.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+def _declared(header):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(fa2_\w+)\s*\(", src)))
 
 
+def declared_functions():
+    return sorted(_declared(HEADER) + _declared(HEADER_BWD))
+
+
 def test_header_and_binding_agree():
-    assert declared_functions() == sorted(_lib.SYMBOLS)
+    assert _declared(HEADER) == sorted(_lib.SYMBOLS)
+    assert _declared(HEADER_BWD) == sorted(_lib.BWD_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
@@ -41,7 +47,8 @@ def test_exported_fa2_symbols_are_only_the_c_abi():
 
 def test_header_compiles_as_plain_c(tmp_path):
     c = tmp_path / "t.c"
-    c.write_text('#include "fa2_fwd.h"\nint main(void){return FA2_OK + (fa2_version()!=0);}\n')
+    c.write_text('#include "fa2_fwd.h"\n#include "fa2_bwd.h"\n'
+                 'int main(void){return FA2_OK + FA2_BWD_VARIANT_AUTO + (fa2_version()!=0);}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
                            str(c), "-o", str(tmp_path / "t.o")])
 
@@ -70,6 +77,28 @@ def _call(N=64, d=64, dtype=_lib.FA2_DTYPE_F32, ptr=0x1000, B=1, H=1, strides=No
 ])
 def test_validation_codes_before_any_launch(kwargs, code, needle):
     assert _call(**kwargs) == code
+    assert needle in _lib.lib().fa2_last_error().decode()
+
+
+def _call_bwd(N=64, d=64, dtype=_lib.FA2_DTYPE_F32, ptr=0x1000, B=1, H=1, dptr=0x1000):
+    s = (H * N * d, N * d, d, 1)
+    i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
+    st = [i64(s) for _ in range(8)]
+    return _lib.lib().fa2_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, dptr, *st, i64((H * N, N)),
+                              B, H, N, d, dtype, 0, 1.0, None)
+
+
+@pytest.mark.parametrize("kwargs,code,needle", [
+    (dict(ptr=0), -1, "null"),
+    (dict(dptr=0), -1, "null"),
+    (dict(B=0), -1, "positive"),
+    (dict(N=0), -3, "N must be"),
+    (dict(d=48), -2, "power of two"),
+    (dict(dtype=_lib.FA2_DTYPE_F8E5M2), -2, "not supported"),
+    (dict(dtype=99), -2, "not supported"),
+])
+def test_backward_validation_codes_before_any_launch(kwargs, code, needle):
+    assert _call_bwd(**kwargs) == code
     assert needle in _lib.lib().fa2_last_error().decode()
 
 

@@ -1,10 +1,15 @@
-"""Counterpart of the reference's src/test_correctness.py (forward half): loop seeds, draw
+"""Counterpart of the reference's src/test_correctness.py (forward AND backward halves): loop seeds, draw
 Q, K, V ~ N(0,1) fp32 of shape (32, 32, 256, 128) ON THE GPU, compare flash_attention_forward with
 torch SDPA(scale=1) on the same tensors using the reference's tolerance
 `allclose(O_torch, O_flash, atol=1e-4, rtol=1e-5)` (src/test_correctness.py:9-14, :28-40).
 
-Differences from the reference script: it is also a pytest test (fewer seeds), it exits non-zero on
-failure when run as a script, and the backward half is out of scope.
+The backward half (src/test_correctness.py:44-76): dO ~ N(0,1), torch.autograd.grad through SDPA vs
+flash_attention_backward(Q, K, V, O_flash, dO, L_flash, deterministic=False / True) with the reference's tolerances
+atol 9e-4 (dQ) / 7e-4 (dK) / 7e-5 (dV), rtol 1e-5.  The backward runs at (8, 8, 256, 128) per seed: autograd through
+the math SDPA at the reference's full (32, 32, 256, 128) needs several GiB of score matrices per seed.
+
+Differences from the reference script: it is also a pytest test (fewer seeds) and it exits non-zero on
+failure when run as a script.
 
     python tests/test_correctness.py            # 200 seeds, prints the reference's summary line
 """
@@ -48,6 +53,30 @@ def run(num_tests=NUM_TESTS, verbose=True):
     return ok, worst
 
 
+def run_backward(num_tests=NUM_TESTS):
+    from flash_attention_dlrs_amd import flash_attention_backward, flash_attention_forward
+    gpu = torch.device("cuda")
+    Bb, Hb = 8, 8
+    res = {k: torch.zeros(num_tests, dtype=torch.int32) for k in ("Q", "K", "V", "det_Q", "det_K", "det_V")}
+    for test in range(num_tests):
+        torch.manual_seed(test)
+        Q, K, V = (torch.randn(Bb, Hb, N, d, device=gpu, dtype=DTYPE, requires_grad=True) for _ in range(3))
+        O_torch = torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1)
+        O_flash, L_flash = flash_attention_forward(Q.detach(), K.detach(), V.detach(), dev=gpu)
+        dO = torch.randn_like(O_torch)
+        g_torch = torch.autograd.grad(O_torch, (Q, K, V), dO)
+        for det in (False, True):
+            g_flash = flash_attention_backward(Q.detach(), K.detach(), V.detach(), O_flash, dO, L_flash, dev=gpu,
+                                               deterministic=det)
+            for k, a, b, atol in zip("QKV", g_torch, g_flash, (9e-4, 7e-4, 7e-5)):
+                res[("det_" if det else "") + k][test] = int(torch.allclose(a, b, atol=atol, rtol=1e-5))
+    for k in ("Q", "K", "V"):
+        print(f"{res[k].sum().item()} out of {num_tests} {k} backward tests succeeded!")
+    for k in ("Q", "K", "V"):
+        print(f"{res['det_' + k].sum().item()} out of {num_tests} deterministic {k} backward tests succeeded!")
+    return {k: int(v.sum().item()) for k, v in res.items()}
+
+
 @pytest.mark.gpu
 def test_reference_correctness_script_forward():
     ok, worst = run(num_tests=12, verbose=False)
@@ -55,7 +84,14 @@ def test_reference_correctness_script_forward():
     assert worst <= 1e-3
 
 
+@pytest.mark.gpu
+def test_reference_correctness_script_backward():
+    res = run_backward(num_tests=6)
+    assert all(v == 6 for v in res.values()), res
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else NUM_TESTS
     ok, _ = run(n)
-    sys.exit(0 if ok == n else 1)
+    res = run_backward(max(n // 10, 1))
+    sys.exit(0 if ok == n and all(v == max(n // 10, 1) for v in res.values()) else 1)
