@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Counterpart of the reference's src/bench.py for the forward mode: sweep N = 2^7 .. 2^15 at B=8, H=16,
+"""Counterpart of the reference's src/bench.py (modes "fwd" and "bwd", src/bench.py:20,93-97): sweep N = 2^7 .. 2^15 at B=8, H=16,
 d=128, fp16 (src/bench.py:8-18), time every provider with do_bench semantics (warm-up ~25 ms, ~100 ms of
 timed repetitions, HIP events per repetition, a cache flush between repetitions; src/bench.py:61-62,99),
 and write the CSV the reference's plotting script reads:
@@ -10,7 +10,9 @@ with an `N` column and one column of mean milliseconds per provider display name
 repository's kernel (in the column the reference gives its own "indet" Triton kernel), torch SDPA default /
 math on the GPU.  The competitor providers of the reference (flash-attn CUDA wheel, OpenAI tutorial) do not
 exist on ROCm and are omitted (NaN columns would break nothing in the plot script, they are simply absent).
-A second file `...-tflops.csv` carries the same sweep as TFLOP/s (4*B*H*N^2*d / t).
+A second file `...-tflops.csv` carries the same sweep as TFLOP/s (4*B*H*N^2*d / t; backward: 2.5 x that,
+the convention of the vendored tutorial, src/flash_attention_openai_tutorial.py:630-635).  Mode "bwd" times
+`O.backward(dO, retain_graph=True)` exactly as the reference does (src/bench.py:93-96).
 """
 import argparse
 import csv
@@ -61,6 +63,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-max-log", type=int, default=N_MAX_log)
     ap.add_argument("--providers", default="hip,torch-sdpa,torch-math")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "bwd"])
     args = ap.parse_args()
     torch.manual_seed(42)  # src/bench.py:26
     gpu = torch.device("cuda")
@@ -72,7 +75,7 @@ def main():
     for N in [2 ** i for i in range(N_MIN_log, args.n_max_log + 1)]:
         row = {"N": float(N)}
         try:
-            Q, K, V = (torch.randn(B, H, N, d, dtype=DTYPE, device=gpu) for _ in range(3))
+            Q, K, V = (torch.randn(B, H, N, d, dtype=DTYPE, device=gpu, requires_grad=args.mode == "bwd") for _ in range(3))
         except torch.cuda.OutOfMemoryError:
             break
         for p in providers:
@@ -85,16 +88,22 @@ def main():
                     with torch.nn.attention.sdpa_kernel(torch.nn.attention.SDPBackend.MATH):
                         return torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1)
             try:
-                if p == "torch-math" and N > 8192:
+                if p == "torch-math" and N > (4096 if args.mode == "bwd" else 8192):
                     raise torch.cuda.OutOfMemoryError()  # N^2 score matrix: 2^15 needs 256 GiB in fp16
-                ms = do_bench(fn)
+                if args.mode == "bwd":  # src/bench.py:93-96
+                    O = fn()
+                    dO = torch.randn_like(O)
+                    bench_fn = lambda: O.backward(dO, retain_graph=True)
+                else:
+                    bench_fn = fn
+                ms = do_bench(bench_fn)
             except (torch.cuda.OutOfMemoryError, RuntimeError) as e:  # reference: NaN on OOM (src/bench.py:100-110)
                 ms = float("nan")
             row[names[p]] = ms
-            print(f"Benchmarking fwd (N={N}, H={H}, B={B}, d={d}) for {p} ... {ms:.4f} ms", flush=True)
+            print(f"Benchmarking {args.mode} (N={N}, H={H}, B={B}, d={d}) for {p} ... {ms:.4f} ms", flush=True)
         rows.append(row)
     os.makedirs(BENCH_DIR, exist_ok=True)
-    base = os.path.join(BENCH_DIR, f"fused-attention-B{B}-H{H}-d{d}-fwd-{dtype_str}")
+    base = os.path.join(BENCH_DIR, f"fused-attention-B{B}-H{H}-d{d}-{args.mode}-{dtype_str}")
     cols = ["N"] + [names[p] for p in providers]
     with open(base + ".csv", "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=cols)
@@ -104,7 +113,8 @@ def main():
         w = csv.DictWriter(f, fieldnames=cols)
         w.writeheader()
         for r in rows:
-            w.writerow({c: (r[c] if c == "N" else 4.0 * B * H * r["N"] ** 2 * d / (r[c] * 1e-3) / 1e12) for c in cols})
+            fl = (10.0 if args.mode == "bwd" else 4.0) * B * H * r["N"] ** 2 * d
+            w.writerow({c: (r[c] if c == "N" else fl / (r[c] * 1e-3) / 1e12) for c in cols})
     print(open(base + "-tflops.csv").read())
 
 

@@ -6,8 +6,13 @@
 // before the second contractions.  The reference sums dQ across key-block programs through a lock; here two
 // launches each OWN their outputs (include/fa2_bwd.h), so nothing is summed across workgroups:
 //
-//   MODE 0  "dK, dV": a wave owns 32 KEYS (K, V row fragments in registers, dK^T and dV^T in 128 accumulators),
-//           the workgroup sweeps the query rows 64 at a time (Q and dO tiles through LDS);
+//   MODE 0  "dK, dV": a wave owns 32 KEYS and ONE of the two gradients: waves 0-3 of the 8-wave workgroup hold dK^T
+//           of key groups 0-3 (K and V fragments in registers), waves 4-7 hold dV^T of the same key groups (K
+//           fragments only); the workgroup sweeps the query rows 64 at a time (Q and dO tiles through LDS).  Both
+//           gradients in one wave need 128 accumulators + 64 fragment registers = one wave per SIMD, measured at 22 %
+//           of the MFMA peak; split, every wave fits 256 registers, two waves share a SIMD, and the two are a dK wave
+//           (24 MFMAs per 32 query rows) and a dV wave (16): different instruction streams that fill each other's
+//           gaps.  The price is S = Q K^T computed by both (5 products per block pair instead of 4);
 //   MODE 1  "dQ":     a wave owns 32 QUERY rows (Q, dO fragments in registers, dQ^T in 64 accumulators),
 //           the workgroup sweeps the keys 64 at a time (K and V tiles through LDS).
 //
@@ -50,6 +55,8 @@ template <> struct Mma<_Float16> {
     }
 };
 
+template <int V> struct IC { static constexpr int value = V; };
+
 struct BArgs {
     const char *Q, *K, *V, *O, *dO, *L;
     char *dQ, *dK, *dV;
@@ -89,10 +96,10 @@ template <typename T, int D> __global__ __launch_bounds__(256) void bwd_D_kernel
 }
 
 template <typename T, int D, int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(const BArgs a) {
+__global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(const BArgs a) {
     using M = Mma<T>;
     using frag = typename M::frag;
-    constexpr int NW = 4, NT = NW * 64, BO = NW * 32, BS = 64;  // owned rows per workgroup, swept rows per tile
+    constexpr int NW = MODE == 0 ? 8 : 4, NT = NW * 64, BO = 128, BS = 64;  // owned rows per workgroup, swept rows per tile
     constexpr int ROWB = D * 2, TILEB = BS * ROWB, CPR = ROWB / 16, CPT = BS * CPR / NT;
     constexpr int RPI = NT / CPR;
     constexpr int KS = D / 16, DB = D / 32;
@@ -100,7 +107,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LDS_PTR(char) lds = (LDS_PTR(char))smem;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: every block / mask decision
+                                                                // below is then a scalar branch, not an EXEC mask
     const int i = lane & 31, h = lane >> 5;
     const int N = a.N;
 
@@ -118,7 +127,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
         }
     }
     const int b = bh / a.H, hh = bh - b * a.H;
-    const int own0 = blk * BO + wave * 32;  // first owned row of this wave
+    const bool roleV = MODE == 0 && wave >= 4;   // MODE 0: waves 4..7 accumulate dV^T, waves 0..3 dK^T
+    const int own0 = blk * BO + (wave & 3) * 32;  // first owned row of this wave
     const int orow = own0 + i;              // this lane's owned row (query in MODE 1, key in MODE 0)
 
     // swept tiles T0, T1 and owned fragments f0, f1
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             f0[ks] = __builtin_bit_cast(frag, *(const u32x4 *)(p0 + ks * 32));
-            f1[ks] = __builtin_bit_cast(frag, *(const u32x4 *)(p1 + ks * 32));
+            if (!roleV) f1[ks] = __builtin_bit_cast(frag, *(const u32x4 *)(p1 + ks * 32));
         }
     }
     // per-lane row constants (MODE 1: the owned query's L and D)
@@ -206,17 +216,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
                 v_off[u][db] = lds_off<D>(8 * u + 4 * h + qq, 4 * db + 2 * w + (pp >> 1)) + 8 * (pp & 1);
     }
 
-    f32x16 acc0[DB], acc1[MODE == 0 ? DB : 1];
+    f32x16 acc0[DB];  // dQ^T (MODE 1), dK^T (MODE 0, waves 0..3) or dV^T (MODE 0, waves 4..7)
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[db][r] = 0.0f;
-    if (MODE == 0) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[db][r] = 0.0f;
-    }
     const float c = a.c_log2e;
     float rsum = 0.0f;  // MODE 1: this lane's share of rowsum(P) of its query
     const bool is_causal = a.causal != 0;
@@ -244,11 +248,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
         // MODE 0 queries of the tile >= first owned key of the wave)
         const bool active = !is_causal || (MODE == 1 ? t * BS <= own0 + 31 : t * BS + BS - 1 >= own0);
         if (active) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int srow0 = t * BS + kb * 32;  // first swept row of this 32-row block
-                if (is_causal && (MODE == 1 ? srow0 > own0 + 31 : srow0 + 31 < own0)) continue;
-                f32x16 x0, x1;
+            auto first = [&](int kb, f32x16 &x0, f32x16 &x1) __attribute__((always_inline)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x0[r] = x1[r] = 0.0f;
                 const int tb = cur * TILEB + kb * 32 * ROWB;
@@ -257,67 +257,77 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
                     const u32x4 t0f = *(LDS_PTR(u32x4))(lds + tb + k_off[ks]);
                     x0 = M::mfma(__builtin_bit_cast(frag, t0f), f0[ks], x0);  // kernels.py:283 (without the log2e factor)
                 }
+                if (!roleV) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const u32x4 t1f = *(LDS_PTR(u32x4))(lds + 2 * TILEB + tb + k_off[ks]);
-                    x1 = M::mfma(__builtin_bit_cast(frag, t1f), f1[ks], x1);  // :289
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const u32x4 t1f = *(LDS_PTR(u32x4))(lds + 2 * TILEB + tb + k_off[ks]);
+                        x1 = M::mfma(__builtin_bit_cast(frag, t1f), f1[ks], x1);  // :289
+                    }
                 }
+            };
+            auto soft = [&](int kb, f32x16 &x0, f32x16 &x1) __attribute__((always_inline)) {
+                const int srow0 = t * BS + kb * 32;  // first swept row of this 32-row block
                 // swept row of register r: srow0 + (r & 3) + 8 (r >> 2) + 4 h
-                float Lr[16], Dr[16];
-                if (MODE == 0) {
+                const bool need_mask = (srow0 + 32 > N) || (is_causal && (MODE == 1 ? srow0 + 31 > own0 : srow0 < own0 + 31));
+                auto body = [&](auto masked_) __attribute__((always_inline)) {
+                    constexpr bool MASKED = decltype(masked_)::value;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 lv = *(LDS_PTR(f32x4))(lds + LOFF + (cur * BS + kb * 32 + 8 * g + 4 * h) * 4);
-                        const f32x4 dv = *(LDS_PTR(f32x4))(lds + LOFF + (2 * BS + cur * BS + kb * 32 + 8 * g + 4 * h) * 4);
+                        f32x4 lv = {Lown, Lown, Lown, Lown}, dv = {Down, Down, Down, Down};
+                        if (MODE == 0) {  // L and D of the four swept query rows 8g + 4h .. + 3
+                            lv = *(LDS_PTR(f32x4))(lds + LOFF + (cur * BS + kb * 32 + 8 * g + 4 * h) * 4);
+                            dv = *(LDS_PTR(f32x4))(lds + LOFF + (2 * BS + cur * BS + kb * 32 + 8 * g + 4 * h) * 4);
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            Lr[4 * g + j] = lv[j];
-                            Dr[4 * g + j] = dv[j];
+                            const int r = 4 * g + j;
+                            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], c, -lv[j]));  // :285
+                            if (MASKED) {
+                                const int srow = srow0 + 8 * g + 4 * h + j;
+                                const int key = MODE == 1 ? srow : orow, qry = MODE == 1 ? orow : srow;
+                                if (srow >= N || (is_causal && key > qry)) p = 0.0f;
+                            }
+                            if (MODE == 1) rsum += p;
+                            x1[r] = roleV ? p : p * (x1[r] - dv[j]);  // :291 (the scale factor is applied once, at the end)
                         }
                     }
-                }
-                const bool need_mask = (srow0 + 32 > N) || (is_causal && (MODE == 1 ? srow0 + 31 > own0 : srow0 < own0 + 31));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float Lv = MODE == 0 ? Lr[r] : Lown, Dv = MODE == 0 ? Dr[r] : Down;
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], c, -Lv));  // :285
-                    if (need_mask) {
-                        const int srow = srow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const int key = MODE == 1 ? srow : orow, qry = MODE == 1 ? orow : srow;
-                        if (srow >= N || (is_causal && key > qry)) p = 0.0f;
-                    }
-                    if (MODE == 1) rsum += p;
-                    x0[r] = p;
-                    x1[r] = p * (x1[r] - Dv);  // :291 (the scale factor is applied once, to the accumulators, at the end)
-                }
-                // second products: k-step ss = swept rows 16ss .. 16ss+15 of the block; registers 8ss..8ss+7 of X are
-                // the B fragment (element j <-> row 16ss + 8(j>>2) + 4h + (j&3)), the A fragment is the transposed read
+                };
+                if (need_mask) body(IC<1>{});
+                else body(IC<0>{});
+            };
+            // second products: k-step ss = swept rows 16ss .. 16ss+15 of the block; registers 8ss..8ss+7 of X are the B
+            // fragment (element j <-> row 16ss + 8(j>>2) + 4h + (j&3)), the A fragment is the transposed read
+            auto second = [&](int kb, f32x16 &x0, f32x16 &x1) __attribute__((always_inline)) {
+                const int tb = (roleV ? 2 * TILEB : 0) + cur * TILEB + kb * 32 * ROWB;  // dV^T = dO^T P reads the dO tile
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
-                    frag dsf, pf;
+                    frag bf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        dsf[j] = (T)x1[8 * ss + j];  // RTNE casts of :293 / :317 and :287
-                        pf[j] = (T)x0[8 * ss + j];
-                    }
+                    for (int j = 0; j < 8; ++j) bf[j] = (T)x1[8 * ss + j];  // RTNE casts of :287 / :293 / :317
                     const int rowb = tb + ss * 16 * ROWB;
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[0][db]));
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[1][db]));
                         const s16x8 tf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc0[db] = M::mfma(__builtin_bit_cast(frag, tf), dsf, acc0[db]);  // :293 / :317
-                    }
-                    if (MODE == 0) {
-#pragma unroll
-                        for (int db = 0; db < DB; ++db) {
-                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + 2 * TILEB + rowb + v_off[0][db]));
-                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + 2 * TILEB + rowb + v_off[1][db]));
-                            const s16x8 tf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                            acc1[db] = M::mfma(__builtin_bit_cast(frag, tf), pf, acc1[db]);  // :287
-                        }
+                        acc0[db] = M::mfma(__builtin_bit_cast(frag, tf), bf, acc0[db]);
                     }
                 }
+            };
+            auto skip = [&](int kb) {
+                const int srow0 = t * BS + kb * 32;
+                return is_causal && (MODE == 1 ? srow0 > own0 + 31 : srow0 + 31 < own0);
+            };
+            const bool do0 = !skip(0), do1 = !skip(1);
+            // (issuing both blocks' first products before any softmax arithmetic was measured SLOWER in the key-owner
+            // mode: two more score tiles push it past 256 arch registers and every use then pays v_accvgpr_read)
+            f32x16 xa0, xa1;
+#pragma nounroll
+            for (int kb = 0; kb < 2; ++kb) {  // not unrolled: two copies of the body cost the key-owner mode 16 spills
+                if (kb == 0 ? !do0 : !do1) continue;
+                first(kb, xa0, xa1);
+                soft(kb, xa0, xa1);
+                second(kb, xa0, xa1);
             }
         }
         if (more) stage_write(cur ^ 1);
@@ -349,9 +359,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void bwd_mfma16_kernel(cons
         if (MODE == 1) {
             store_rows(a.dQ, a.dqs, acc0, a.scale / tot);
             if (h == 0) Lc[orow] = Lown + __builtin_amdgcn_logf(tot);
-        } else {
+        } else if (!roleV) {
             store_rows(a.dK, a.dks, acc0, a.scale);
-            store_rows(a.dV, a.dvs, *(f32x16(*)[DB]) & acc1, 1.0f);
+        } else {
+            store_rows(a.dV, a.dvs, acc0, 1.0f);
         }
     }
 }
@@ -367,7 +378,7 @@ template <typename T, int D> int launch_d(const Fa2BwdProblem &p, const BArgs &a
     constexpr size_t smem0 = 4 * 64 * D * 2 + 4 * 64 * 4, smem1 = 4 * 64 * D * 2;
     // the query-owner launch goes first: it leaves the fp32 row statistic the key-owner launch reads
     hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 1>), dim3((unsigned)nblk), dim3(256), smem1, p.stream, a);
-    hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 0>), dim3((unsigned)nblk), dim3(256), smem0, p.stream, a);
+    hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 0>), dim3((unsigned)nblk), dim3(512), smem0, p.stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fa2_set_error("backward mfma16 launch failed: %s", hipGetErrorString(e));
