@@ -126,6 +126,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(co
             blk = bid % nblk;
         }
     }
+    if (MODE == 1 && a.causal) blk = nblk - 1 - blk;  // causal: the last query blocks sweep the most keys -- start them first
     const int b = bh / a.H, hh = bh - b * a.H;
     const bool roleV = MODE == 0 && wave >= 4;   // MODE 0: waves 4..7 accumulate dV^T, waves 0..3 dK^T
     const int own0 = blk * BO + (wave & 3) * 32;  // first owned row of this wave
@@ -240,6 +241,91 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(co
     }
     __syncthreads();
 
+    if constexpr (MODE == 0) {
+        // ---- key-owner launch.  The dV wave and the dK wave of a key group (waves kg + 4 and kg: one SIMD) share P
+        // through LDS instead of both computing S = Q K^T:
+        //     dV wave, step b:   S_b (8 MFMA), P_b = exp2(c S_b - L) -> its fp32 accumulator image to slot[kg][b & 1],
+        //                        dV^T += dO_b^T P_b (8 MFMA)
+        //     dK wave, step b:   block b - 1:  dP (8 MFMA), P from slot[kg][(b - 1) & 1], dS = P (dP - D),
+        //                        dK^T += Q^T dS (8 MFMA)
+        // one barrier per step publishes the slot written in it (and, every second step, the next Q / dO tile): the dK
+        // wave runs one 32-row block behind, whose tile is still resident -- tile t+1 is written into the buffer of tile
+        // t-1 at the END of step 2t+1, after the dK wave's last use of tile t-1 in step 2t.  16 + 16 MFMAs per block.
+        constexpr int POFF = LOFF + 4 * BS * 4;  // P slots: [4 key groups][2][4 KiB]
+        const int kg = wave & 3;
+        auto blk_skip = [&](int bidx) {  // causal: all 32 queries of the block precede all 32 keys of the wave
+            return is_causal && bidx * 32 + 31 < own0;
+        };
+        auto blk_masked = [&](int bidx) { return (bidx * 32 + 32 > N) || (is_causal && bidx * 32 < own0 + 31); };
+        for (int sidx = 2 * t_begin; sidx <= 2 * t_end; ++sidx) {
+            const int t = sidx >> 1, kb = sidx & 1;
+            if (kb == 0 && t + 1 < t_end) stage_load(t + 1);
+            const int bidx = roleV ? sidx : sidx - 1;  // the block this wave works on in this step
+            const bool work = roleV ? sidx < 2 * t_end : sidx - 1 >= 2 * t_begin;
+            if (work && !blk_skip(bidx)) {
+                const int cur = (bidx >> 1) & 1, kbb = bidx & 1, srow0 = bidx * 32;
+                const int tb = cur * TILEB + kbb * 32 * ROWB;
+                const int slot = POFF + (kg * 2 + (bidx & 1)) * 4096 + lane * 16;
+                f32x16 x;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+                if (roleV) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const u32x4 qf = *(LDS_PTR(u32x4))(lds + tb + k_off[ks]);
+                        x = M::mfma(__builtin_bit_cast(frag, qf), f0[ks], x);  // kernels.py:283 (without the log2e factor)
+                    }
+                    const bool masked = blk_masked(bidx);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 lv = *(LDS_PTR(f32x4))(lds + LOFF + (cur * BS + kbb * 32 + 8 * g + 4 * h) * 4);
+                        f32x4 pv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j], c, -lv[j]));  // :285
+                            if (masked) {
+                                const int qry = srow0 + 8 * g + 4 * h + j;
+                                if (qry >= N || (is_causal && orow > qry)) pe = 0.0f;
+                            }
+                            pv[j] = pe;
+                            x[4 * g + j] = pe;
+                        }
+                        *(LDS_PTR(f32x4))(lds + slot + g * 1024) = pv;
+                    }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const u32x4 gf = *(LDS_PTR(u32x4))(lds + 2 * TILEB + tb + k_off[ks]);
+                        x = M::mfma(__builtin_bit_cast(frag, gf), f1[ks], x);  // :289
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 dv = *(LDS_PTR(f32x4))(lds + LOFF + (2 * BS + cur * BS + kbb * 32 + 8 * g + 4 * h) * 4);
+                        const f32x4 pv = *(LDS_PTR(f32x4))(lds + slot + g * 1024);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[4 * g + j] = pv[j] * (x[4 * g + j] - dv[j]);  // :291
+                    }
+                }
+                const int tbase = (roleV ? 2 * TILEB : 0) + tb;  // dV^T = dO^T P reads the dO tile, dK^T = Q^T dS the Q tile
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    frag bf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bf[j] = (T)x[8 * ss + j];  // RTNE casts of :287 / :293
+                    const int rowb = tbase + ss * 16 * ROWB;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[0][db]));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[1][db]));
+                        const s16x8 tf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc0[db] = M::mfma(__builtin_bit_cast(frag, tf), bf, acc0[db]);
+                    }
+                }
+            }
+            if (kb == 1 && t + 1 < t_end) stage_write((t + 1) & 1);
+            __syncthreads();
+        }
+    } else
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = t & 1;
         const bool more = t + 1 < t_end;
@@ -375,9 +461,14 @@ template <typename T, int D> int launch_d(const Fa2BwdProblem &p, const BArgs &a
         fa2_set_error("backward mfma16: grid too large");
         return FA2_ERR_BAD_ARG;
     }
-    constexpr size_t smem0 = 4 * 64 * D * 2 + 4 * 64 * 4, smem1 = 4 * 64 * D * 2;
+    constexpr size_t smem0 = 4 * 64 * D * 2 + 4 * 64 * 4 + 4 * 2 * 4096, smem1 = 4 * 64 * D * 2;
     // the query-owner launch goes first: it leaves the fp32 row statistic the key-owner launch reads
     hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 1>), dim3((unsigned)nblk), dim3(256), smem1, p.stream, a);
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)bwd_mfma16_kernel<T, D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem0);
+        attr_set = true;
+    }
     hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 0>), dim3((unsigned)nblk), dim3(512), smem0, p.stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
