@@ -201,6 +201,25 @@ def main():
         torch.cuda.synchronize(dev)
         extras["tflops_inputs_scaled_d^-1/4"] = round(F / (a.elapsed_time(b) / 100 * 1e-3) / 1e12, 2)
         del Q2, K2
+        # (1b) the backward of the same workload (the reference bench's default mode,
+        # src/bench.py:20): D + dQ + dK/dV launches of include/fa2_bwd.h, TFLOP/s at the 2.5 x forward convention
+        if c["dtype"] in ("bf16", "fp16", "f32"):
+            from flash_attention_dlrs_amd import flash_attention_backward
+            O, Ls = flash_attention_forward(Q, K, V, dev, causal=c["causal"])
+            dO = torch.randn_like(Q)
+            for _ in range(5):
+                flash_attention_backward(Q, K, V, O, dO, Ls, dev, causal=c["causal"])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            a.record()
+            for _ in range(20):
+                flash_attention_backward(Q, K, V, O, dO, Ls, dev, causal=c["causal"])
+            b.record()
+            torch.cuda.synchronize(dev)
+            tb = a.elapsed_time(b) / 20
+            extras["backward"] = {"ms": round(tb, 4), "tflops_2.5x_fwd_convention": round(2.5 * F / (tb * 1e-3) / 1e12, 2),
+                                  "launches": "D, dQ (query-block owner), dK/dV (key-block owner); deterministic"}
+            del O, Ls, dO
         # (2) the optional exchange step: all-gather of the O shards over xGMI, overlapped per batch element
         if world > 1:
             for _ in range(2):
