@@ -16,7 +16,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, autotune
 
 MIN_TENSOR_SIZE = 16
 
@@ -82,7 +82,10 @@ def _forward_impl(ctx, Q, K, V, causal, scale):
     O = torch.empty_like(Q)
     L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=Q.device)
 
-    _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale)
+    # static gfx950 tile table, or the on-box tuner's choice when FA2_AUTOTUNE=1 (autotune.py; reference:
+    # the Triton autotuner keyed on (B, H, N, d), kernels.py:11-15)
+    _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale,
+                 variant=autotune.pick(Q, K, V, O, L, dtype, causal, scale))
 
     ctx.save_for_backward(Q, K, V, O, L)
     ctx.padded = padded

@@ -5,7 +5,7 @@ script (src/test_correctness.py:34) and the only place the log2-domain log-sum-e
 """
 import torch
 
-from . import _lib
+from . import _lib, autotune
 from .flash_attention_torch import (MIN_TENSOR_SIZE, backward_native, convert_triton_dtype, next_power_of_2,
                                     pad_last_dim)
 
@@ -29,8 +29,11 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
     O = torch.empty(B, H, N, d_pow, dtype=Q.dtype, device=dev)
     L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=dev)
 
-    _lib.fa2_fwd(Q, K, V, O, L, convert_triton_dtype(Q.dtype), causal=causal, scale=scale,
-                 variant=_lib.VARIANTS[variant])
+    dtype = convert_triton_dtype(Q.dtype)
+    v = _lib.VARIANTS[variant]
+    if variant == "auto":
+        v = autotune.pick(Q, K, V, O, L, dtype, causal, scale)  # VARIANT_AUTO unless FA2_AUTOTUNE=1
+    _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
 
     return O[:, :, :, 0:d], L
 

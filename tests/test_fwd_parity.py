@@ -13,6 +13,7 @@ Tolerances (stated once):
   fp8       >= 95 % of elements equal to the oracle's fp8 value, the rest within one fp8 ulp
   L         fp32 5e-5 * max(1,|L|) ; fp16/bf16 one ulp of the dtype at |L|
 """
+import json
 import math
 
 import numpy as np
@@ -419,3 +420,23 @@ def test_d_inv_quarter_scaled_inputs_c3_shape():
     for causal in (False, True):
         O, _ = fa.flash_attention_forward(Q, K, V, DEV, causal=causal)
         assert (O.float() - sdpa_ref(Q, K, V, causal)).abs().max().item() <= 1e-2
+
+
+def test_runtime_tuner_picks_a_parity_tested_variant(tmp_path, oracle):
+    """with the on-box tuner enabled the first call measures the candidates, persists the
+    choice, and the result stays within the documented tolerance whichever variant wins."""
+    from flash_attention_dlrs_amd import autotune
+    Q, K, V = _rand((1, 8, 512, 128), torch.bfloat16, seed=77)
+    O_ref, _ = _oracle(oracle, Q, K, V, torch.bfloat16, True)
+    path = str(tmp_path / "tile_table.json")
+    autotune.enable(True, path)
+    try:
+        O, _ = fa.flash_attention_forward(Q.to(DEV), K.to(DEV), V.to(DEV), DEV, causal=True)
+        table = json.load(open(path))
+        (key, entry), = table.items()
+        assert key == "bfloat16:d128:N512:causal:small" and entry["variant"] in _lib.VARIANTS and "auto" in entry["ms"]
+        O2, _ = fa.flash_attention_forward(Q.to(DEV), K.to(DEV), V.to(DEV), DEV, causal=True)  # served from the table
+        assert torch.equal(O, O2)
+    finally:
+        autotune.enable(False)
+    assert (O.float().cpu() - O_ref).abs().max() <= O_TOL[torch.bfloat16]

@@ -89,3 +89,28 @@ def test_library_missing_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback|not built"):
         _lib.lib()
+
+
+def test_autotune_key_and_table_roundtrip(tmp_path, monkeypatch):
+    """The tuner's key ignores B and H except through the small / large grid class, buckets N, and the table
+    persists (reference: autotune key (B, H, N, d), kernels.py:13).  No GPU: only the bookkeeping is exercised."""
+    from flash_attention_dlrs_amd import autotune
+    q = lambda B, H, N, d, dt=torch.bfloat16: torch.empty(B, H, N, d, dtype=dt)
+    assert autotune.key_of(q(4, 32, 4096, 128), True) == "bfloat16:d128:N4096:causal:large"
+    assert autotune.key_of(q(8, 16, 4096, 128), True) == autotune.key_of(q(4, 32, 4096, 128), True)
+    assert autotune.key_of(q(1, 2, 3000, 128), False) == "bfloat16:d128:N4096:full:small"
+    assert autotune.key_of(q(1, 2, 128, 64, torch.float16), False) == "float16:d64:N128:full:small"
+    path = str(tmp_path / "t.json")
+    autotune.enable(True, path)
+    try:
+        autotune._load()["bfloat16:d128:N4096:causal:large"] = {"variant": "mfma16d", "ms": {}}
+        autotune._save()
+        autotune.enable(True, path)  # drops the in-memory copy
+        assert autotune._load()["bfloat16:d128:N4096:causal:large"]["variant"] == "mfma16d"
+        # a known key is answered from the table without touching the GPU
+        Q = q(4, 32, 4096, 128)
+        assert autotune.pick(Q, Q, Q, Q, Q, _lib.FA2_DTYPE_BF16, True, 1.0) == _lib.VARIANT_MFMA16D
+    finally:
+        autotune.enable(False)
+    Q = q(4, 32, 4096, 128)
+    assert autotune.pick(Q, Q, Q, Q, Q, _lib.FA2_DTYPE_BF16, True, 1.0) == _lib.VARIANT_AUTO
