@@ -73,6 +73,17 @@ template <int D> __device__ __forceinline__ int lds_off(int row, int ch) {
     else return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
 }
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// One LDS-DMA piece (64 lanes x 16 bytes, lane-linear in LDS); inline asm and our own vmcnt wait, as in fa2_mfma16d.hip
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_base, int voffset) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(voffset), "s"(rsrc)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- D[b, h, n] = sum_x O * dO  (kernels.py:115-166): D/8 lanes per row, 16 bytes of each operand per lane
 template <typename T, int D> __global__ __launch_bounds__(256) void bwd_D_kernel(const BArgs a) {
     constexpr int LPR = D / 8;  // lanes per row
@@ -95,11 +106,12 @@ template <typename T, int D> __global__ __launch_bounds__(256) void bwd_D_kernel
     if (r < rows && ch == 0) a.D[r] = s;
 }
 
-template <typename T, int D, int MODE>
-__global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(const BArgs a) {
+template <typename T, int D, int MODE, int NWQ = 4>
+__global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kernel(const BArgs a) {
     using M = Mma<T>;
     using frag = typename M::frag;
-    constexpr int NW = MODE == 0 ? 8 : 4, NT = NW * 64, BO = 128, BS = 64;  // owned rows per workgroup, swept rows per tile
+    // owned rows per workgroup (MODE 1: NWQ waves x 32 query rows), swept rows per tile
+    constexpr int NW = MODE == 0 ? 8 : NWQ, NT = NW * 64, BO = MODE == 0 ? 128 : NWQ * 32, BS = 64;
     constexpr int ROWB = D * 2, TILEB = BS * ROWB, CPR = ROWB / 16, CPT = BS * CPR / NT;
     constexpr int RPI = NT / CPR;
     constexpr int KS = D / 16, DB = D / 32;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(co
     if (MODE == 1 && a.causal) blk = nblk - 1 - blk;  // causal: the last query blocks sweep the most keys -- start them first
     const int b = bh / a.H, hh = bh - b * a.H;
     const bool roleV = MODE == 0 && wave >= 4;   // MODE 0: waves 4..7 accumulate dV^T, waves 0..3 dK^T
-    const int own0 = blk * BO + (wave & 3) * 32;  // first owned row of this wave
+    const int own0 = blk * BO + (MODE == 0 ? wave & 3 : wave) * 32;  // first owned row of this wave
     const int orow = own0 + i;              // this lane's owned row (query in MODE 1, key in MODE 0)
 
     // swept tiles T0, T1 and owned fragments f0, f1
@@ -169,22 +181,37 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(co
     const int wg0 = blk * BO;
     int t_begin = 0, t_end = (N + BS - 1) / BS;
 
-    const int st_row = tid / CPR, st_ch = tid % CPR;
-    const char *g0 = T0p + (int64_t)st_row * t0rs + st_ch * 16;
-    const char *g1 = T1p + (int64_t)st_row * t1rs + st_ch * 16;
-    const int st_lds = lds_off<D>(st_row, st_ch);
-    static_assert(RPI % 16 == 0, "staging pass must cover a multiple of 16 rows");
-
-    u32x4 r0[CPT], r1[CPT];
-    float lreg = 0.0f, dreg = 0.0f;  // MODE 0: threads 0..63 stage L and D of the swept query rows
-    auto stage_load = [&](int t) {
+    // ---- staging of the swept tiles by LDS-DMA (buffer_load ... lds): 1 KiB pieces, wave w issues pieces w, w + NW, ...;
+    // lane l of piece p fills LDS (row = RPP p + l / CPR, slot = l % CPR) with global chunk slot ^ f(row) -- the swizzle
+    // goes through the SOURCE address, the descriptor's range check zero-fills rows past N.
+    constexpr int RPP = 1024 / ROWB, PIECES = TILEB / 1024, PPW = PIECES / NW;
+    static_assert(PPW >= 1, "too many waves for this tile");
+    auto make_rsrc = [&](const char *base, int bytes) {
+        const uint64_t ba = (uint64_t)base;
+        i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)ba);
+        r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(ba >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane(bytes);
+        r[3] = 0x00020000;
+        return r;
+    };
+    const i32x4 rs0 = make_rsrc(T0p, (N - 1) * (int)t0rs + ROWB), rs1 = make_rsrc(T1p, (N - 1) * (int)t1rs + ROWB);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+    int so0[PPW], so1[PPW];
 #pragma unroll
-        for (int it = 0; it < CPT; ++it) {
-            const int row = t * BS + it * RPI + st_row;
-            const bool ok = row < N;
-            const int64_t ro = (int64_t)(t * BS + it * RPI);
-            r0[it] = ok ? *(const u32x4 *)(g0 + ro * t0rs) : u32x4{0, 0, 0, 0};
-            r1[it] = ok ? *(const u32x4 *)(g1 + ro * t1rs) : u32x4{0, 0, 0, 0};
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int row = RPP * (wave + pp * NW) + lane / CPR, slot = lane % CPR;
+        const int chunk = slot ^ ((lds_off<D>(row, 0) - row * ROWB) >> 4);
+        so0[pp] = row * (int)t0rs + chunk * 16;
+        so1[pp] = row * (int)t1rs + chunk * 16;
+    }
+    float lreg = 0.0f, dreg = 0.0f;  // MODE 0: threads 0..63 stage L and D of the swept query rows
+    auto stage_load = [&](int t) {  // the target buffer t & 1 must be free when this is called
+        const int buf = t & 1;
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            dma16(rs0, lds_base + buf * TILEB + (wave + pp * NW) * 1024, so0[pp] + t * BS * (int)t0rs);
+            dma16(rs1, lds_base + 2 * TILEB + buf * TILEB + (wave + pp * NW) * 1024, so1[pp] + t * BS * (int)t1rs);
         }
         if (MODE == 0 && tid < BS) {
             const int row = t * BS + tid;
@@ -192,16 +219,12 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(co
             dreg = row < N ? Dp[row] : 0.0f;
         }
     };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < CPT; ++it) {
-            *(LDS_PTR(u32x4))(lds + buf * TILEB + st_lds + it * RPI * ROWB) = r0[it];
-            *(LDS_PTR(u32x4))(lds + 2 * TILEB + buf * TILEB + st_lds + it * RPI * ROWB) = r1[it];
-        }
+    auto stage_write = [&](int buf) {  // this wave's pieces have landed; the barrier that follows publishes them
         if (MODE == 0 && tid < BS) {
             *(LDS_PTR(float))(lds + LOFF + (buf * BS + tid) * 4) = lreg;
             *(LDS_PTR(float))(lds + LOFF + (2 * BS + buf * BS + tid) * 4) = dreg;
         }
+        dma_wait();
     };
 
     int k_off[KS];  // row read: row kb*32 + i, chunk 2ks + h
@@ -259,7 +282,8 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, 2) void bwd_mfma16_kernel(co
         auto blk_masked = [&](int bidx) { return (bidx * 32 + 32 > N) || (is_causal && bidx * 32 < own0 + 31); };
         for (int sidx = 2 * t_begin; sidx <= 2 * t_end; ++sidx) {
             const int t = sidx >> 1, kb = sidx & 1;
-            if (kb == 0 && t + 1 < t_end) stage_load(t + 1);
+            // tile t+1 goes into the buffer of tile t-1, which the dK waves still read in the kb == 0 step
+            if (kb == 1 && t + 1 < t_end) stage_load(t + 1);
             const int bidx = roleV ? sidx : sidx - 1;  // the block this wave works on in this step
             const bool work = roleV ? sidx < 2 * t_end : sidx - 1 >= 2 * t_begin;
             if (work && !blk_skip(bidx)) {
@@ -463,7 +487,12 @@ template <typename T, int D> int launch_d(const Fa2BwdProblem &p, const BArgs &a
     }
     constexpr size_t smem0 = 4 * 64 * D * 2 + 4 * 64 * 4 + 4 * 2 * 4096, smem1 = 4 * 64 * D * 2;
     // the query-owner launch goes first: it leaves the fp32 row statistic the key-owner launch reads
-    hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 1>), dim3((unsigned)nblk), dim3(256), smem1, p.stream, a);
+    if (fa2_env_int("FA2_BWD_DQ_WAVES", 4) == 8) {
+        const long long nblk8 = (long long)((p.N + 255) / 256) * p.B * p.H;
+        hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 1, 8>), dim3((unsigned)nblk8), dim3(512), smem1, p.stream, a);
+    } else {
+        hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 1, 4>), dim3((unsigned)nblk), dim3(256), smem1, p.stream, a);
+    }
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)bwd_mfma16_kernel<T, D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem0);
@@ -496,6 +525,9 @@ bool fa2_bwd_mfma16_supports(const Fa2BwdProblem &p) {
     for (int t = 0; t < 8; ++t)
         if (!aligned16(ptrs[t])) return false;
     if (p.N > (1 << 24)) return false;
+    // 32-bit buffer offsets of the LDS-DMA staging: (N + 64) rows of every swept tensor below 2 GiB
+    for (int t = 0; t < 5; ++t)
+        if ((int64_t)(p.N + 64) * all[t][2] * 2 >= (1LL << 31)) return false;
     return true;
 }
 
