@@ -57,6 +57,10 @@ template <> struct Mma<_Float16> {
 
 template <int V> struct IC { static constexpr int value = V; };
 
+#ifndef FA2_BWD_PIPE
+#define FA2_BWD_PIPE 0  // measured: 41-45 spills, 27 % slower (two more score tiles do not fit 256 registers)
+#endif
+
 struct BArgs {
     const char *Q, *K, *V, *O, *dO, *L;
     char *dQ, *dK, *dV;
@@ -432,12 +436,24 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
             // (issuing both blocks' first products before any softmax arithmetic was measured SLOWER in the key-owner
             // mode: two more score tiles push it past 256 arch registers and every use then pays v_accvgpr_read)
             f32x16 xa0, xa1;
+            if (FA2_BWD_PIPE && do0 && do1) {
+                // both blocks' first products go out before any softmax arithmetic: the exp2 / dS arithmetic of block 0
+                // runs under the MFMAs of block 1, that of block 1 under the second products of block 0
+                f32x16 xb0, xb1;
+                first(0, xa0, xa1);
+                first(1, xb0, xb1);
+                soft(0, xa0, xa1);
+                second(0, xa0, xa1);
+                soft(1, xb0, xb1);
+                second(1, xb0, xb1);
+            } else {
 #pragma nounroll
-            for (int kb = 0; kb < 2; ++kb) {  // not unrolled: two copies of the body cost the key-owner mode 16 spills
-                if (kb == 0 ? !do0 : !do1) continue;
-                first(kb, xa0, xa1);
-                soft(kb, xa0, xa1);
-                second(kb, xa0, xa1);
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 0 ? !do0 : !do1) continue;
+                    first(kb, xa0, xa1);
+                    soft(kb, xa0, xa1);
+                    second(kb, xa0, xa1);
+                }
             }
         }
         if (more) stage_write(cur ^ 1);

@@ -373,21 +373,52 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
         constexpr int PD = 3;  // read-ahead distance in steps; the ring holds ops n .. n+PD
         float rs[QB] = {0.0f, 0.0f};
         // element pair q = 0..15: query block q & 1, elements 2(q>>1), 2(q>>1)+1.  Pairs 0..7 (P of keys 0..15,
-        // both query blocks) are due before step 8, all of them before step 12.
-        auto do_pair = [&](int q) {
+        // both query blocks) are due before step 8, all of them before step 12.  The arithmetic of a pair is spread
+        // over THREE consecutive steps -- F: t = s*c - m at step E-1, E: p = exp2(t) at step E, A/C: row sum and cvt at
+        // step E+1 -- so that no instruction waits on the one issued just before it (in-kernel stamps on
+        // fa2_mfma16h.hip: the fma, exp2, add sequence on one element made the phase dependency-latency bound, and
+        // with ONE wave per SIMD nothing else covers such a stall).
+        constexpr int ESTEP[16] = {0, 0, 1, 1, 2, 3, 3, 4, 5, 5, 6, 7, 7, 8, 9, 10};
+        auto stageF = [&](int q) {
             const int qb = q & 1;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * (q >> 1) + e;
-                float p;
-                if constexpr (ABL & 1) p = sCur[qb][r];
-                else {
-                    p = __builtin_amdgcn_exp2f(__builtin_fmaf(sCur[qb][r], c, -m[qb]));
-                    rs[qb] += p;
-                }
-                pf[qb][r >> 3][r & 7] = (T)p;
+                if constexpr (!(ABL & 1)) sCur[qb][r] = __builtin_fmaf(sCur[qb][r], c, -m[qb]);
             }
         };
+        auto stageE = [&](int q) {
+            const int qb = q & 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * (q >> 1) + e;
+                if constexpr (!(ABL & 1)) sCur[qb][r] = __builtin_amdgcn_exp2f(sCur[qb][r]);
+            }
+        };
+        auto stageAC = [&](int q) {
+            const int qb = q & 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * (q >> 1) + e;
+                if constexpr (!(ABL & 1)) rs[qb] += sCur[qb][r];
+                pf[qb][r >> 3][r & 7] = (T)sCur[qb][r];
+            }
+        };
+        auto softmax_step = [&](int st) {  // st = 0..15, compile-time constant at every call site
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (ESTEP[q] == st + 1) stageF(q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (ESTEP[q] == st) stageE(q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (ESTEP[q] == st - 1) stageAC(q);
+        };
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (ESTEP[q] == 0) stageF(q);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             issue(ks + PD);
@@ -402,8 +433,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
                     sNxt[qb] = M::mfma(ring[ks & 3], qf[qb][ks], sNxt[qb]);
                 }
             }
-            do_pair(ks + (ks + 1) / 2);                       // steps 0..7 take 2,1,2,1,2,1,2,1 pairs: 0..11
-            if ((ks & 1) == 0) do_pair(ks + (ks + 1) / 2 + 1);
+            softmax_step(ks);
             staging(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_mfma16x_kernel(const XArgs a) 
             issue(8 + st + PD);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) o[qb][db] = M::mfma(ring[(8 + st) & 3], pf[qb][ss], o[qb][db]);
-            if (st < 4) do_pair(12 + st);
+            softmax_step(8 + st);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if constexpr (ABL & 2) {
