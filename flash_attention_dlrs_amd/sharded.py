@@ -87,3 +87,19 @@ def flash_attention_forward_sharded(Q, K, V, *, group=None, causal=False, scale=
         main.wait_stream(comm)
     L_local = torch.cat(L_parts, dim=0)
     return O_full, (L_full if gather_L else L_local)
+
+
+def _default_local_backward(Q, K, V, O, dO, L, causal, scale):
+    from .flash_attention_wrappers import flash_attention_backward
+    return flash_attention_backward(Q, K, V, O, dO, L, Q.device, causal=causal, scale=scale)
+
+
+def flash_attention_backward_sharded(Q, K, V, O, dO, L, *, causal=False, scale=1.0, local_backward=None):
+    """Backward on this rank's head shard: (dQ, dK, dV) of the local heads, shapes (B, H/G, N, d).
+
+    No collective: the gradient of head h depends only on head h's Q, K, V, O, dO, L (reference bwd_kernel,
+    kernels.py:222-225: programs are indexed (j, b, h) and never communicate across (b, h)), so each rank's
+    gradients ARE its shard of the full gradients -- slice of the single-GPU result bit for bit.  If dO arrives as the
+    full (B, H, N, d) tensor (e.g. from a loss computed on gathered outputs), pass `shard_heads(dO, G, rank)`."""
+    bwd = local_backward or _default_local_backward
+    return bwd(Q, K, V, O, dO, L, causal, scale)

@@ -25,6 +25,13 @@ def _oracle_local_forward(Q, K, V, causal, scale):
     return torch.from_numpy(O), torch.from_numpy(L)
 
 
+def _oracle_local_backward(Q, K, V, O, dO, L, causal, scale):
+    from oracle import fa2_oracle
+    g = fa2_oracle.backward(Q.numpy(), K.numpy(), V.numpy(), O.numpy(), dO.numpy(), L.numpy(), "float32",
+                            causal=causal, scale=scale)
+    return tuple(torch.from_numpy(x) for x in g[:3])
+
+
 def _worker(rank, world, port, causal, out_dir):
     import sys
     sys.path.insert(0, ROOT)
@@ -45,6 +52,14 @@ def _worker(rank, world, port, causal, out_dir):
         assert torch.equal(O_full, O_one) and torch.equal(L_full, L_one)      # bit-identical head indexing
         assert torch.equal(O_loc, shard_heads(O_one, world, rank))
         assert torch.equal(L_loc, shard_heads(L_one, world, rank))
+        # backward: no collective, the local gradients are the rank's slice of the full gradients, bit for bit
+        from flash_attention_dlrs_amd.sharded import flash_attention_backward_sharded
+        dO = torch.randn(B, H, N, d)
+        g_loc = flash_attention_backward_sharded(q, k, v, O_loc, shard_heads(dO, world, rank).contiguous(), L_loc,
+                                                 causal=causal, local_backward=_oracle_local_backward)
+        g_one = _oracle_local_backward(Q, K, V, O_one, dO, L_one, causal, 1.0)
+        for a, b_ in zip(g_loc, g_one):
+            assert torch.equal(a, shard_heads(b_, world, rank))
         np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([1]))
     finally:
         dist.destroy_process_group()
