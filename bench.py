@@ -37,6 +37,10 @@ CONFIGS = {  # BASELINE.json "configs"
     "ref_test": dict(B=32, H=32, N=256, d=128, dtype="f32", causal=False),  # src/test_correctness.py:9-14
     "f32_long": dict(B=2, H=16, N=4096, d=128, dtype="f32", causal=False),
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
+    "d64_long": dict(B=8, H=16, N=4096, d=64, dtype="fp16", causal=False),
+    "d64_long_causal": dict(B=8, H=16, N=4096, d=64, dtype="bf16", causal=True),
+    "n1024": dict(B=8, H=32, N=1024, d=128, dtype="bf16", causal=False),
+    "n2048": dict(B=16, H=64, N=2048, d=128, dtype="bf16", causal=False),
     "c3_fp8": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=True),
     "c5_per_gpu": dict(B=16, H=8, N=16384, d=128, dtype="fp8", causal=False),   # BASELINE.json configs[4], one GPU's head shard
 }

@@ -64,7 +64,11 @@ int pick_variant(const Fa2Problem &p) {
                             (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
         if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
-        return wg256 >= 512 ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16D_W4;
+        if (wg256 < 512) return FA2_VARIANT_MFMA16D_W4;
+        // 8-wave tiles.  MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop) measured against
+        // MFMA16D on MI355X: non-causal +4.4 % (d = 128, N = 4096), +4.8 % (N = 8192), +3 % (N = 1024), +9 % (d = 64);
+        // causal d = 64 +3 %, causal d = 128 -2..-4 % (the north-star shape stays on MFMA16D).
+        return (p.causal && p.d == 128) ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16H;
     }
     if (fa2_mfma8_supports(p)) {
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;

@@ -466,8 +466,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             constexpr int PAR = decltype(par_)::value;
             constexpr int KCUR = (PAR ^ 1) * TILEB;  // K unit t+1: rows 0..31 = block 2t+1, rows 32..63 = block 2t+2
             constexpr int VCUR = PAR * TILEB;        // V tile t:   rows 0..31 = block 2t,   rows 32..63 = block 2t+1
+            // FA2_FLAGS & 2: alternate the issue priority between the two halves of the workgroup, waves NW/2.. first in
+            // step A, waves 0..NW/2-1 first in step B (in-kernel stamps: with equal priority the older half wins every
+            // arbitration, finishes ~900 cycles early and waits at the barrier while its SIMD partners run alone)
+            if (a.flags & 2) {
+                if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<0>{}, sA, sB, fireA, coeffA);
             pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, t, PAR ^ 1, sA, sB, fireB, coeffB);
+            if (a.flags & 2) {
+                if (wave >= NW / 2) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(1);
+            }
             qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, sB, sA, fireB, coeffB);
             pv_phase(IC<VCUR + 32 * ROWB>{}, IC<-1>{}, -1, 0, sB, sA, fireA, coeffA);
             dma_wait();  // this wave's pieces of (K unit t+2, V tile t+1) have landed; the barrier publishes them
