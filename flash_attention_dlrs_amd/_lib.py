@@ -36,7 +36,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_
 SYMBOLS = ("fa2_fwd", "fa2_fwd_variant", "fa2_query_tile", "fa2_version", "fa2_last_error")
 # ... and include/fa2_bwd.h
 BWD_SYMBOLS = ("fa2_bwd", "fa2_bwd_variant")
-BWD_VARIANTS = {"auto": 0, "generic": 1, "mfma16": 2}
+BWD_VARIANTS = {"auto": 0, "generic": 1, "mfma16": 2, "mfma32": 3}
 
 _lib = None
 

@@ -47,10 +47,14 @@ int validate(const Fa2BwdProblem &p) {
 int run(const Fa2BwdProblem &p, int variant) {
     const int rc = validate(p);
     if (rc != FA2_OK) return rc;
-    if (variant == FA2_BWD_VARIANT_AUTO) variant = fa2_bwd_mfma16_supports(p) ? FA2_BWD_VARIANT_MFMA16 : FA2_BWD_VARIANT_GENERIC;
+    if (variant == FA2_BWD_VARIANT_AUTO)
+        variant = fa2_bwd_mfma16_supports(p)   ? FA2_BWD_VARIANT_MFMA16
+                  : fa2_bwd_mfma32_supports(p) ? FA2_BWD_VARIANT_MFMA32
+                                               : FA2_BWD_VARIANT_GENERIC;
     switch (variant) {
     case FA2_BWD_VARIANT_GENERIC: return fa2_bwd_launch_generic(p);
     case FA2_BWD_VARIANT_MFMA16: return fa2_bwd_launch_mfma16(p);
+    case FA2_BWD_VARIANT_MFMA32: return fa2_bwd_launch_mfma32(p);
     default: fa2_set_error("unknown backward kernel variant %d", variant); return FA2_ERR_BAD_ARG;
     }
 }

@@ -18,3 +18,5 @@ struct Fa2BwdProblem {
 int fa2_bwd_launch_generic(const Fa2BwdProblem &p);
 int fa2_bwd_launch_mfma16(const Fa2BwdProblem &p);
 bool fa2_bwd_mfma16_supports(const Fa2BwdProblem &p);
+int fa2_bwd_launch_mfma32(const Fa2BwdProblem &p);
+bool fa2_bwd_mfma32_supports(const Fa2BwdProblem &p);

@@ -38,6 +38,7 @@ extern "C" {
 #define FA2_BWD_VARIANT_AUTO 0
 #define FA2_BWD_VARIANT_GENERIC 1 /* any dtype but fp8, any strides, d = 2^k in [16,512], any N; VALU            */
 #define FA2_BWD_VARIANT_MFMA16 2  /* f16 / bf16, d in {64,128}, unit d-stride, 16-byte aligned rows; MFMA        */
+#define FA2_BWD_VARIANT_MFMA32 3  /* f32 via v_mfma_f32_32x32x2_f32 (exact fp32), d in {64,128}, same layout rules */
 
 /*
  * dQ, dK, dV = gradients of  O = softmax(scale * Q K^T [+ causal mask]) V  given dO, with P recomputed from the

@@ -35,6 +35,8 @@ def variants_for(dtype, d):
     v = ["auto", "generic"]
     if dtype in (torch.float16, torch.bfloat16) and d in (64, 128):
         v.append("mfma16")
+    if dtype == torch.float32 and d in (64, 128):
+        v.append("mfma32")
     return v
 
 
