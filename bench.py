@@ -40,6 +40,9 @@ CONFIGS = {  # BASELINE.json "configs"
     "d64_long": dict(B=8, H=16, N=4096, d=64, dtype="fp16", causal=False),
     "d64_long_causal": dict(B=8, H=16, N=4096, d=64, dtype="bf16", causal=True),
     "n1024": dict(B=8, H=32, N=1024, d=128, dtype="bf16", causal=False),
+    "causal_16k": dict(B=1, H=32, N=16384, d=128, dtype="bf16", causal=True),
+    "causal_8k": dict(B=2, H=32, N=8192, d=128, dtype="bf16", causal=True),
+    "causal_2k": dict(B=8, H=32, N=2048, d=128, dtype="bf16", causal=True),
     "n2048": dict(B=16, H=64, N=2048, d=128, dtype="bf16", causal=False),
     "c3_fp8": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=True),
     "c5_per_gpu": dict(B=16, H=8, N=16384, d=128, dtype="fp8", causal=False),   # BASELINE.json configs[4], one GPU's head shard
