@@ -45,10 +45,7 @@ template <> struct Mma<_Float16> {
     }
 };
 
-template <int V> struct IC {
-    static constexpr int value = V;
-    constexpr operator int() const { return V; }
-};
+template <int V> struct IC { static constexpr int value = V; };
 
 struct DmaArgs {
     const char *Q, *K, *V;
@@ -126,6 +123,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
     // and Q rows are already in flight while this job's O leaves.  4-wave build (two workgroups per CU, LDS is the
     // limit): the slices alias the K/V buffers and the next job's loads start after the epilogue.
     constexpr bool EPI_SEP = NW == 8;
+#ifndef FA2_STAGGER
+#define FA2_STAGGER 0
+#endif
+    constexpr bool STAGGER = FA2_STAGGER != 0;
     constexpr int EPI0 = EPI_SEP ? 4 * TILEB : 0;
     constexpr int RPI = 64 / CPR;                  // rows per epilogue store instruction (4 at d = 128, 8 at d = 64)
     constexpr int NST = 32 / RPI + 1;              // store instructions per wave and job: O rows + L
@@ -267,6 +268,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
         }
         return fire;
     };
+    auto finish = [&](f32x16 &s, frag (&pf)[2]) {
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -m));
+            rs += p;
+            pf[r >> 3][r & 7] = (T)p;
+        }
+        lsum += rs;
+    };
     auto rescale = [&](bool fire, float coeff) __attribute__((always_inline)) {
         if (fire) {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -281,6 +292,18 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             asm volatile("s_nop 7" ::: "memory");
             lsum *= coeff;
         }
+    };
+    auto pv = [&](frag (&pf)[2], int voff) {  // voff = buffer base + half * 32 rows
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int rowb = voff + ss * 16 * ROWB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[0][db]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + rowb + v_off[1][db]));
+                const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = M::mfma(__builtin_bit_cast(frag, vf), pf[ss], o[db]);
+            }
     };
     auto block_masked = [&](int j) __attribute__((always_inline)) { return (CAUSAL && (j * 32 + 31 > q0)) || (j * 32 + 32 > N); };
 
@@ -367,15 +390,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             }
         };
         // QK phase of a block step: S_next = K_blk . Q^T (KS MFMAs) under P = exp2(S_cur * c - m); fetches the later K
-        // fragments and the first V fragments of this step's P.V.  HAS_NEXT = false (the wave's last block: nothing left
-        // to score) keeps only the softmax pipeline and the V fetches.  Offsets are IC<> constants in the steady loop
-        // (LDS addresses = base register + immediate) and plain ints in the diagonal / tail iterations.
-        auto qk_phase = [&](auto kimm_, auto vimm_, auto pref_in_, auto has_next_, f32x16 &sCur, f32x16 &sNext, bool fireCur,
-                            float coeffCur) __attribute__((always_inline)) {
-            const int KIMM = kimm_, VIMM = vimm_;
-            constexpr bool PREF_IN = decltype(pref_in_)::value, HAS_NEXT = decltype(has_next_)::value;
+        // fragments and the first V fragments of this step's P.V.
+        auto qk_phase = [&](auto kimm_, auto vimm_, auto pref_in_, f32x16 &sCur, f32x16 &sNext, bool fireCur, float coeffCur) __attribute__((always_inline)) {
+            constexpr int KIMM = decltype(kimm_)::value, VIMM = decltype(vimm_)::value;
+            constexpr bool PREF_IN = decltype(pref_in_)::value;
             rescale(fireCur, coeffCur);
-            if (HAS_NEXT && !PREF_IN) {
+            if (!PREF_IN) {
 #pragma unroll
                 for (int ks = 0; ks < R; ++ks) kf[ks] = read_k(KIMM, ks);
             }
@@ -384,18 +404,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (HAS_NEXT) {
-                    if (ks == 0) {
-                        f32x16 z;
+                if (ks == 0) {
+                    f32x16 z;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                        sNext = M::mfma(kf[0], qf[0], z);
-                    } else {
-                        sNext = M::mfma(kf[ks % R], qf[ks], sNext);
-                    }
-                    if (ks < R) kf[ks] = read_k(KIMM, ks + R);
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    sNext = M::mfma(kf[0], qf[0], z);
+                } else {
+                    sNext = M::mfma(kf[ks % R], qf[ks], sNext);
                 }
-                if (ks >= R) vf[ks - R] = read_v(VIMM, ks - R);
+                if (ks < R) kf[ks] = read_k(KIMM, ks + R);
+                else vf[ks - R] = read_v(VIMM, ks - R);
                 if (ks + 1 < KS) stageF(sCur, ks + 1);
                 stageE(sCur, ks);
                 if (ks >= 1) stageAC(sCur, ks - 1);
@@ -404,23 +422,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
         };
         // PV phase: O^T += V_blk^T . P^T (KS MFMAs, MFMA-paced) under the row maximum of S_next; carries the DMA pieces
         // of iteration DMA_T (if >= 0) and the first K fragments of the next QK phase (if that block is published).
-        // HAS_NEXT = false: no next block, no maximum, no decision.  MASKED: S_next is the wave's diagonal block or
-        // reaches past N -- the mask of block jnext goes on before the maximum.
-        auto pv_phase = [&](auto vimm_, auto kpref_, auto has_next_, auto masked_, const int DMA_T, const int v_dma_buf,
-                            const int jnext, f32x16 &sCur, f32x16 &sNext, bool &fireNext, float &coeffNext)
-                            __attribute__((always_inline)) {
-            const int VIMM = vimm_, KPREF = kpref_;
-            constexpr bool PREF_OUT = !__is_same(decltype(kpref_), int);  // prefetch only from compile-time offsets
-            constexpr bool HAS_NEXT = decltype(has_next_)::value, MASKED = decltype(masked_)::value;
+        auto pv_phase = [&](auto vimm_, auto kpref_, const int DMA_T, const int v_dma_buf, f32x16 &sCur, f32x16 &sNext,
+                            bool &fireNext, float &coeffNext) __attribute__((always_inline)) {
+            constexpr int VIMM = decltype(vimm_)::value, KPREF = decltype(kpref_)::value;
+            constexpr bool PREF_OUT = KPREF >= 0;
             float mx = -INFINITY;
-            if (HAS_NEXT && MASKED) {
-                int lim = N - 1;
-                if (CAUSAL) lim = qrow < lim ? qrow : lim;
-                const int klim = lim - (jnext * 32 + 4 * h);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((r & 3) + 8 * (r >> 2) > klim) sNext[r] = -INFINITY;
-            }
 #pragma unroll
             for (int idx = 0; idx < KS; ++idx) {
                 if (idx == 0) {
@@ -429,99 +435,121 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
                 }
                 o[idx % DB] = M::mfma(vf[idx % R], pf[idx / DB], o[idx % DB]);
                 if (idx < R) vf[idx] = read_v(VIMM, idx + R);
-                else if (PREF_OUT && HAS_NEXT) kf[idx - R] = read_k(KPREF, idx - R);
+                else if (PREF_OUT) kf[idx - R] = read_k(KPREF, idx - R);
                 if (DMA_T >= 0 && idx < 2 * PPW) {
                     const int pp = idx % PPW;
                     if (idx < PPW) dma16(krsrc, lds_base + (DMA_T & 1) * TILEB + (wave + pp * NW) * 1024, kvo[pp] + ((DMA_T + 2) * 64 - 32) * krs);
                     else dma16(vrsrc, lds_base + VBASE + v_dma_buf * TILEB + (wave + pp * NW) * 1024, vvo[pp] + (DMA_T + 1) * 64 * vrs);
                 }
-                if (HAS_NEXT && idx >= S0) {
+                if (idx >= S0) {
                     const int lo = 16 * (idx - S0) / (KS - S0), hi = 16 * (idx + 1 - S0) / (KS - S0);
 #pragma unroll
                     for (int r = lo; r < hi; ++r) mx = fmaxf(mx, sNext[r]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            fireNext = false;
+            mx = half_swap_max(mx) * c;
+            fireNext = !__all(mx - m <= kThr);
             coeffNext = 1.0f;
-            if (HAS_NEXT) {
-                mx = half_swap_max(mx) * c;
-                fireNext = !__all(mx - m <= kThr);
-                if (fireNext) {
-                    const float m_new = fmaxf(m, mx);
-                    coeffNext = __builtin_amdgcn_exp2f(m - m_new);
-                    m = m_new;
-                }
+            if (fireNext) {
+                const float m_new = fmaxf(m, mx);
+                coeffNext = __builtin_amdgcn_exp2f(m - m_new);
+                m = m_new;
             }
         };
+        // The two halves of the workgroup run the four phases of an iteration ONE PHASE APART (waves w and w + NW/2
+        // share a SIMD): group X does QK.PV.QK.PV, group Y does PV.QK.PV.QK with its first PV finishing the previous
+        // iteration's second block -- so a SIMD always pairs a VALU-bound QK phase with an MFMA-paced PV phase instead
+        // of running two of a kind against each other (in-kernel stamps: lockstep waves took the SUM of their phases).
+        const bool groupY = STAGGER && wave >= NW / 2;
         auto iterX = [&](auto par_, int t) __attribute__((always_inline)) {  // par_ = t & 1
             constexpr int PAR = decltype(par_)::value;
             constexpr int KCUR = (PAR ^ 1) * TILEB;  // K unit t+1: rows 0..31 = block 2t+1, rows 32..63 = block 2t+2
             constexpr int VCUR = PAR * TILEB;        // V tile t:   rows 0..31 = block 2t,   rows 32..63 = block 2t+1
             // FA2_FLAGS & 2: alternate the issue priority between the two halves of the workgroup, waves NW/2.. first in
             // step A, waves 0..NW/2-1 first in step B (in-kernel stamps: with equal priority the older half wins every
-            // arbitration, finishes ~900 cycles early and waits at the barrier while its SIMD partners run alone).
-            // Measured: no gain from the priorities themselves -- but the two scalar branches are kept: with them hipcc
-            // schedules the phases 3.5 % faster (non-causal c3 shape, three devices).
+            // arbitration, finishes ~900 cycles early and waits at the barrier while its SIMD partners run alone)
             if (a.flags & 2) {
                 if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
-            qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<0>{}, IC<1>{}, sA, sB, fireA, coeffA);
-            pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, IC<1>{}, IC<0>{}, t, PAR ^ 1, 0, sA, sB, fireB, coeffB);
+            qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<0>{}, sA, sB, fireA, coeffA);
+            pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, t, PAR ^ 1, sA, sB, fireB, coeffB);
             if (a.flags & 2) {
                 if (wave >= NW / 2) __builtin_amdgcn_s_setprio(0);
                 else __builtin_amdgcn_s_setprio(1);
             }
-            qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, IC<1>{}, sB, sA, fireB, coeffB);
-            pv_phase(IC<VCUR + 32 * ROWB>{}, 0, IC<1>{}, IC<0>{}, -1, 0, 0, sB, sA, fireA, coeffA);
+            qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, sB, sA, fireB, coeffB);
+            pv_phase(IC<VCUR + 32 * ROWB>{}, IC<-1>{}, -1, 0, sB, sA, fireA, coeffA);
             dma_wait();  // this wave's pieces of (K unit t+2, V tile t+1) have landed; the barrier publishes them
             __syncthreads();
         };
-        int t = 0;
-        for (; t + 1 < t_steady; t += 2) {
-            iterX(IC<0>{}, t);
-            iterX(IC<1>{}, t + 1);
-        }
-        if (t < t_steady) {  // odd count: t is even here, one more hand-ordered iteration instead of the general path
-            iterX(IC<0>{}, t);
-            ++t;
-        }
-        // ---- diagonal / tail iterations: the same phases with run-time offsets, guarded per block.  A wave's blocks are
-        // 0 .. nb-1; block j is masked if it is the wave's diagonal block or reaches past N.
-        auto tail_half = [&](int j, int koff, int voff, f32x16 &sCur, f32x16 &sNext, bool &fireCur, float &coeffCur,
-                             bool &fireNext, float &coeffNext) __attribute__((always_inline)) {
-            if (j >= nb) return;  // this wave is done (it still takes part in the DMA and the barriers)
-            if (j + 1 < nb) {
-                qk_phase(koff, voff, IC<0>{}, IC<1>{}, sCur, sNext, fireCur, coeffCur);
-                if (block_masked(j + 1)) pv_phase(voff, 0, IC<1>{}, IC<1>{}, -1, 0, j + 1, sCur, sNext, fireNext, coeffNext);
-                else pv_phase(voff, 0, IC<1>{}, IC<0>{}, -1, 0, j + 1, sCur, sNext, fireNext, coeffNext);
+        auto iterY = [&](auto par_, auto first_, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_)::value;
+            constexpr int KCUR = (PAR ^ 1) * TILEB, VCUR = PAR * TILEB, VPREV = (PAR ^ 1) * TILEB;
+            if (decltype(first_)::value) {
+                dma_k(t + 2, PAR);
+                dma_v(t + 1, PAR ^ 1);
             } else {
-                qk_phase(koff, voff, IC<0>{}, IC<0>{}, sCur, sNext, fireCur, coeffCur);
-                pv_phase(voff, 0, IC<0>{}, IC<0>{}, -1, 0, j + 1, sCur, sNext, fireNext, coeffNext);
+                pv_phase(IC<VPREV + 32 * ROWB>{}, IC<KCUR>{}, t, PAR ^ 1, sB, sA, fireA, coeffA);
             }
+            qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<1>{}, sA, sB, fireA, coeffA);
+            pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, -1, 0, sA, sB, fireB, coeffB);
+            qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, sB, sA, fireB, coeffB);
+            dma_wait();
+            __syncthreads();
         };
-        // one block per trip, the two score tiles swapped at the end of a trip (32 register moves): a single set of phase
-        // bodies serves both halves of an iteration -- instantiated per half they cost 77-152 spilled registers
-#pragma nounroll
-        for (int j = 2 * t; j < 2 * nt; ++j) {
-            const int tt = j >> 1, half = j & 1;
-            if (half == 0 && tt + 1 < nt) {
-                dma_k(tt + 2, tt & 1);
-                dma_v(tt + 1, (tt + 1) & 1);
+        int t = 0;
+        if (!groupY) {
+            for (; t + 1 < t_steady; t += 2) {
+                iterX(IC<0>{}, t);
+                iterX(IC<1>{}, t + 1);
             }
-            const int koff = ((tt + 1) & 1) * TILEB + half * 32 * ROWB;  // K unit tt+1, V tile tt
-            const int voff = (tt & 1) * TILEB + half * 32 * ROWB;
-            tail_half(j, koff, voff, sA, sB, fireA, coeffA, fireB, coeffB);
-            {
-                const f32x16 ts = sA; sA = sB; sB = ts;
-                const bool tf = fireA; fireA = fireB; fireB = tf;
-                const float tc = coeffA; coeffA = coeffB; coeffB = tc;
+            if (t < t_steady) {  // odd count: t is even here, one more hand-ordered iteration instead of the general path
+                iterX(IC<0>{}, t);  // (causal c3: -2.8 % -> parity with mfma16d; N = 8192 causal: -1.8 % -> +2.2 %)
+                ++t;
             }
-            if (half == 1) {
-                dma_wait();
-                __syncthreads();
+            // (routing the diagonal / tail iterations through these phases too -- run-time offsets, HAS_NEXT / MASKED
+            // variants -- was built and is correct, but the extra phase bodies cost 77-152 spilled registers and 15 %)
+        } else if (t_steady >= 2) {
+#pragma unroll
+            for (int ks = 0; ks < R; ++ks) kf[ks] = read_k(TILEB, ks);  // K unit 1 rows 0..31 (iteration 0's first block)
+            iterY(IC<0>{}, IC<1>{}, 0);
+            iterY(IC<1>{}, IC<0>{}, 1);
+            for (t = 2; t + 1 < t_steady; t += 2) {
+                iterY(IC<0>{}, IC<0>{}, t);
+                iterY(IC<1>{}, IC<0>{}, t + 1);
             }
+            // group Y's deferred P.V of the last steady block
+            pv_phase(IC<TILEB + 32 * ROWB>{}, IC<-1>{}, -1, 0, sB, sA, fireA, coeffA);
+        }
+        for (; t < nt; ++t) {
+            const bool more = t + 1 < nt;
+            if (more) {
+                dma_k(t + 2, t & 1);
+                dma_v(t + 1, (t + 1) & 1);
+            }
+            const int kcur = ((t + 1) & 1) * TILEB;
+            const int vcur = (t & 1) * TILEB;
+            const int jA = 2 * t, jB = 2 * t + 1, jA2 = 2 * t + 2;
+            if (jA < nb) rescale(fireA, coeffA);
+            if (jB < nb) qk(sB, kcur);
+            if (jA < nb) {
+                finish(sA, pf);
+                pv(pf, vcur);
+            }
+            if (jB < nb) {
+                fireB = partial(sB, jB, coeffB, block_masked(jB));
+                rescale(fireB, coeffB);
+            }
+            if (jA2 < nb) qk(sA, kcur + 32 * ROWB);
+            if (jB < nb) {
+                finish(sB, pf);
+                pv(pf, vcur + 32 * ROWB);
+            }
+            if (jA2 < nb) fireA = partial(sA, jA2, coeffA, block_masked(jA2));
+            dma_wait();
+            __syncthreads();
         }
 
         // ---- this job's output addressing, then the NEXT job (its loads go out before the epilogue below)
