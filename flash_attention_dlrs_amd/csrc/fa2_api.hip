@@ -68,7 +68,9 @@ int pick_variant(const Fa2Problem &p) {
         // 8-wave tiles.  MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop) measured against
         // MFMA16D on MI355X: non-causal +4.4 % (d = 128, N = 4096), +4.8 % (N = 8192), +3 % (N = 1024), +9 % (d = 64);
         // causal d = 64 +3 %, causal d = 128 -2..-4 % (the north-star shape stays on MFMA16D).
-        return (p.causal && p.d == 128) ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16H;
+        // (with the odd steady iteration on the hand-ordered path: causal d = 128 on par at N = 4096, +2 % at 8192,
+        // -2 % at 2048 -- the diagonal iterations still take the general path there)
+        return (p.causal && p.d == 128 && p.N < 8192) ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16H;
     }
     if (fa2_mfma8_supports(p)) {
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
