@@ -371,12 +371,27 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
                     const u32x4 t0f = *(LDS_PTR(u32x4))(lds + tb + k_off[ks]);
                     x0 = M::mfma(__builtin_bit_cast(frag, t0f), f0[ks], x0);  // kernels.py:283 (without the log2e factor)
                 }
-                if (!roleV) {
+                // dP = dO V^T (8 MFMAs) with P = exp2(c S - L) of the finished S tile underneath: one fenced step per MFMA
+                // carrying the fma + exp2 of 16/KS elements, one step behind so that the first exp2 does not wait for the
+                // last S MFMA (this launch is the query owner: L is a per-lane constant).  Masks are applied in soft().
+                constexpr int EP = 16 / KS;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        const u32x4 t1f = *(LDS_PTR(u32x4))(lds + 2 * TILEB + tb + k_off[ks]);
-                        x1 = M::mfma(__builtin_bit_cast(frag, t1f), f1[ks], x1);  // :289
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 t1f = *(LDS_PTR(u32x4))(lds + 2 * TILEB + tb + k_off[ks]);
+                    x1 = M::mfma(__builtin_bit_cast(frag, t1f), f1[ks], x1);  // :289
+                    if (ks >= 1) {
+#pragma unroll
+                        for (int e = 0; e < EP; ++e) {
+                            const int r = (ks - 1) * EP + e;
+                            x0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], c, -Lown));  // :285
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < EP; ++e) {
+                    const int r = (KS - 1) * EP + e;
+                    x0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], c, -Lown));
                 }
             };
             auto soft = [&](int kb, f32x16 &x0, f32x16 &x1) __attribute__((always_inline)) {
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int r = 4 * g + j;
-                            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], c, -lv[j]));  // :285
+                            float p = x0[r];  // exp2(c S - L), computed under the dP MFMAs in first()
                             if (MASKED) {
                                 const int srow = srow0 + 8 * g + 4 * h + j;
                                 const int key = MODE == 1 ? srow : orow, qry = MODE == 1 ? orow : srow;
