@@ -142,9 +142,13 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
             blk = bid % nblk;
         }
     }
-    if (MODE == 1 && a.causal) blk = nblk - 1 - blk;  // causal: the last query blocks sweep the most keys -- start them first
+    if (MODE == 1 && (a.causal & 1)) blk = nblk - 1 - blk;  // causal: the last query blocks sweep the most keys -- start them first
     const int b = bh / a.H, hh = bh - b * a.H;
     const bool roleV = MODE == 0 && wave >= 4;   // MODE 0: waves 4..7 accumulate dV^T, waves 0..3 dK^T
+    // The dV waves carry the exp2 work and are the second-dispatched half, which loses every issue arbitration to the
+    // older half: in-kernel stamps showed them at 2 900 busy cycles per block step against 1 950 for the dK waves, which
+    // then waited 1 100 cycles at the barrier.  FA2_BWD_PRIO (default 1): static priority for the dV waves.
+    if (MODE == 0 && roleV && (a.causal & 2)) __builtin_amdgcn_s_setprio(1);
     const int own0 = blk * BO + (MODE == 0 ? wave & 3 : wave) * 32;  // first owned row of this wave
     const int orow = own0 + i;              // this lane's owned row (query in MODE 1, key in MODE 0)
 
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
         for (int r = 0; r < 16; ++r) acc0[db][r] = 0.0f;
     const float c = a.c_log2e;
     float rsum = 0.0f;  // MODE 1: this lane's share of rowsum(P) of its query
-    const bool is_causal = a.causal != 0;
+    const bool is_causal = (a.causal & 1) != 0;
     if (is_causal) {
         if (MODE == 1) {
             const int last = (wg0 + BO - 1 < N - 1 ? wg0 + BO - 1 : N - 1);
@@ -576,7 +580,8 @@ int fa2_bwd_launch_mfma16(const Fa2BwdProblem &p) {
         a.dos[k] = p.dos[k] * 2; a.dqs[k] = p.dqs[k] * 2; a.dks[k] = p.dks[k] * 2; a.dvs[k] = p.dvs[k] * 2;
     }
     a.ls[0] = p.ls[0]; a.ls[1] = p.ls[1];
-    a.B = p.B; a.H = p.H; a.N = p.N; a.causal = p.causal;
+    a.B = p.B; a.H = p.H; a.N = p.N;
+    a.causal = (p.causal ? 1 : 0) | (fa2_env_int("FA2_BWD_PRIO", 1) ? 2 : 0);  // bit 1: static priority for the dV waves
     a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
     a.scale = p.scale;
     if (p.dtype == FA2_DTYPE_BF16) return p.d == 128 ? launch_d<__bf16, 128>(p, a) : launch_d<__bf16, 64>(p, a);
