@@ -86,6 +86,13 @@ __device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_base, int v
                  : "s"(lds_base), "v"(voffset), "s"(rsrc)
                  : "memory");
 }
+__device__ __forceinline__ void dma4(const i32x4 rsrc, unsigned lds_base, int voffset) {  // 64 lanes x 4 bytes
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(voffset), "s"(rsrc)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- D[b, h, n] = sum_x O * dO  (kernels.py:115-166): D/8 lanes per row, 16 bytes of each operand per lane
@@ -213,7 +220,10 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
         so0[pp] = row * (int)t0rs + chunk * 16;
         so1[pp] = row * (int)t1rs + chunk * 16;
     }
-    float lreg = 0.0f, dreg = 0.0f;  // MODE 0: threads 0..63 stage L and D of the swept query rows
+    // MODE 0: the row statistics L and D of the 64 swept query rows travel by LDS-DMA too (two 256-byte pieces issued by
+    // wave 0; rows past N read as 0 and are masked like every other out-of-range row) -- staged through registers they
+    // cost wave 0 a global-load wait of ~480 cycles per tile (in-kernel stamps)
+    const i32x4 rsL = make_rsrc((const char *)Lc, N * 4), rsD = make_rsrc((const char *)Dp, N * 4);
     auto stage_load = [&](int t) {  // the target buffer t & 1 must be free when this is called
         const int buf = t & 1;
 #pragma unroll
@@ -221,19 +231,12 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
             dma16(rs0, lds_base + buf * TILEB + (wave + pp * NW) * 1024, so0[pp] + t * BS * (int)t0rs);
             dma16(rs1, lds_base + 2 * TILEB + buf * TILEB + (wave + pp * NW) * 1024, so1[pp] + t * BS * (int)t1rs);
         }
-        if (MODE == 0 && tid < BS) {
-            const int row = t * BS + tid;
-            lreg = row < N ? Lc[row] : INFINITY;  // P = exp2(.. - inf) = 0 for rows past N
-            dreg = row < N ? Dp[row] : 0.0f;
+        if (MODE == 0 && wave == 0) {
+            dma4(rsL, lds_base + LOFF + buf * BS * 4, (t * BS + lane) * 4);
+            dma4(rsD, lds_base + LOFF + (2 * BS + buf * BS) * 4, (t * BS + lane) * 4);
         }
     };
-    auto stage_write = [&](int buf) {  // this wave's pieces have landed; the barrier that follows publishes them
-        if (MODE == 0 && tid < BS) {
-            *(LDS_PTR(float))(lds + LOFF + (buf * BS + tid) * 4) = lreg;
-            *(LDS_PTR(float))(lds + LOFF + (2 * BS + buf * BS + tid) * 4) = dreg;
-        }
-        dma_wait();
-    };
+    auto stage_write = [&](int) { dma_wait(); };  // this wave's pieces have landed; the barrier that follows publishes them
 
     int k_off[KS];  // row read: row kb*32 + i, chunk 2ks + h
 #pragma unroll
