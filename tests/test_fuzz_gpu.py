@@ -1,0 +1,66 @@
+"""Randomised shape sweep of the forward and the backward on the GPU against fp64 truth (torch autograd through a plain
+fp64 softmax(QK^T)V on the same device): catches indexing mistakes that fixed shape lists miss -- N around every tile
+boundary (32 / 64 / 128 / 256 and the causal tile pairs), B*H multiples of 8 and not (XCD mapping), d in {16..256},
+both 16-bit dtypes and fp32, causal and not, every kernel variant the problem supports.  Seeded: the same cases every run."""
+import math
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import flash_attention_dlrs_amd as fa  # noqa: E402
+
+DEV = torch.device("cuda:0")
+REL = {torch.float32: 3e-5, torch.float16: 4e-3, torch.bfloat16: 2.5e-2}
+
+
+def truth(Q, K, V, dO, causal):
+    q, k, v = (t.double().detach().requires_grad_(True) for t in (Q, K, V))
+    S = q @ k.transpose(-1, -2)
+    if causal:
+        N = Q.shape[2]
+        S = S.masked_fill(~torch.ones(N, N, dtype=torch.bool, device=Q.device).tril(), float("-inf"))
+    O = torch.softmax(S, dim=-1) @ v
+    g = torch.autograd.grad(O, (q, k, v), dO.double())
+    return O.detach(), g
+
+
+def cases():
+    rng = random.Random(20261004)
+    edges = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 640, 769, 1023, 1025]
+    out = []
+    for k in range(48):
+        N = rng.choice(edges) if k % 3 else rng.randint(1, 1100)
+        d = rng.choice([16, 32, 64, 64, 128, 128, 128, 256])
+        B, H = rng.choice([(1, 1), (1, 3), (2, 4), (1, 8), (3, 8), (2, 5)])
+        dtype = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
+        out.append((B, H, N, d, dtype, bool(k & 1)))
+    return out
+
+
+@pytest.mark.parametrize("B,H,N,d,dtype,causal", cases(), ids=lambda v: str(v).replace("torch.", ""))
+def test_random_shape(B, H, N, d, dtype, causal):
+    g = torch.Generator().manual_seed(B * 1000003 + H * 10007 + N * 101 + d)
+    spread = 1.0 if dtype == torch.float32 else 0.6
+    Q, K, V, dO = ((torch.randn(B, H, N, d, generator=g) * spread).to(dtype).to(DEV) for _ in range(4))
+    O_t, g_t = truth(Q, K, V, dO, causal)
+    fwd_variants = ["auto", "generic"]
+    if dtype != torch.float32 and d in (64, 128):
+        fwd_variants += ["mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4"] + (["mfma16x", "mfma16s"] if d == 128 else [])
+    if dtype == torch.float32 and d in (64, 128):
+        fwd_variants += ["mfma32"]
+    for v in fwd_variants:
+        O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal, variant=v)
+        err = (O.double() - O_t).abs().max().item()
+        assert err <= REL[dtype] * max(1.0, O_t.abs().max().item()) * (4 if dtype == torch.float32 else 1), ("fwd", v, err)
+    O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal)
+    bwd_variants = ["auto", "generic"]
+    for v in bwd_variants:
+        grads = fa.flash_attention_backward(Q, K, V, O, dO, L, DEV, causal=causal, variant=v)
+        for name, a, t in zip("QKV", grads, g_t):
+            err = (a.double() - t).abs().max().item()
+            bound = (2e-4 if dtype == torch.float32 else REL[dtype]) * max(1.0, t.abs().max().item())
+            assert err <= bound, ("bwd", v, name, err, bound)
+    assert math.isfinite(L.float().abs().max().item())
