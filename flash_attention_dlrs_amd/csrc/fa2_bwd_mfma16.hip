@@ -191,6 +191,11 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
         Lown = (float)Lp[row];
         Down = Dp[row];
     }
+    // Wait for the owned fragments HERE.  Their first use is inside the sweep loop, and hipcc puts its counted
+    // `s_waitcnt vmcnt(7..0)` in front of those MFMAs, in every iteration -- where the counter also holds the LDS-DMA
+    // pieces just issued for the next tile (inline asm, invisible to the compiler), so each iteration waited for its own
+    // prefetch to land.  An explicit wait the compiler can see empties its scoreboard before the loop.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
 
     // swept range (causal: MODE 1 keys <= last owned query; MODE 0 queries >= first owned key)
     const int wg0 = blk * BO;
@@ -310,23 +315,26 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
                         const u32x4 qf = *(LDS_PTR(u32x4))(lds + tb + k_off[ks]);
                         x = M::mfma(__builtin_bit_cast(frag, qf), f0[ks], x);  // kernels.py:283 (without the log2e factor)
                     }
-                    const bool masked = blk_masked(bidx);
+                    auto pbody = [&](auto masked_) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 lv = *(LDS_PTR(f32x4))(lds + LOFF + (cur * BS + kbb * 32 + 8 * g + 4 * h) * 4);
-                        f32x4 pv;
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 lv = *(LDS_PTR(f32x4))(lds + LOFF + (cur * BS + kbb * 32 + 8 * g + 4 * h) * 4);
+                            f32x4 pv;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j], c, -lv[j]));  // :285
-                            if (masked) {
-                                const int qry = srow0 + 8 * g + 4 * h + j;
-                                if (qry >= N || (is_causal && orow > qry)) pe = 0.0f;
+                            for (int j = 0; j < 4; ++j) {
+                                float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j], c, -lv[j]));  // :285
+                                if (decltype(masked_)::value) {
+                                    const int qry = srow0 + 8 * g + 4 * h + j;
+                                    if (qry >= N || (is_causal && orow > qry)) pe = 0.0f;
+                                }
+                                pv[j] = pe;
+                                x[4 * g + j] = pe;
                             }
-                            pv[j] = pe;
-                            x[4 * g + j] = pe;
+                            *(LDS_PTR(f32x4))(lds + slot + g * 1024) = pv;
                         }
-                        *(LDS_PTR(f32x4))(lds + slot + g * 1024) = pv;
-                    }
+                    };
+                    if (blk_masked(bidx)) pbody(IC<1>{});  // one wave-uniform branch, two straight-line bodies
+                    else pbody(IC<0>{});
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
