@@ -123,8 +123,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
     using frag = typename M::frag;
     // owned rows per workgroup (MODE 1: NWQ waves x 32 query rows), swept rows per tile
     constexpr int NW = MODE == 0 ? 8 : NWQ, NT = NW * 64, BO = MODE == 0 ? 128 : NWQ * 32, BS = 64;
-    constexpr int ROWB = D * 2, TILEB = BS * ROWB, CPR = ROWB / 16, CPT = BS * CPR / NT;
-    constexpr int RPI = NT / CPR;
+    constexpr int ROWB = D * 2, TILEB = BS * ROWB, CPR = ROWB / 16;
     constexpr int KS = D / 16, DB = D / 32;
     constexpr int LOFF = 4 * TILEB;  // LDS: T0[2] | T1[2] | L[2][64] | D[2][64] (floats; MODE 0 only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
