@@ -122,7 +122,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
     using M = Mma<T>;
     using frag = typename M::frag;
     // owned rows per workgroup (MODE 1: NWQ waves x 32 query rows), swept rows per tile
-    constexpr int NW = MODE == 0 ? 8 : NWQ, NT = NW * 64, BO = MODE == 0 ? 128 : NWQ * 32, BS = 64;
+    constexpr int NW = MODE == 0 ? 8 : NWQ, BO = MODE == 0 ? 128 : NWQ * 32, BS = 64;
     constexpr int ROWB = D * 2, TILEB = BS * ROWB, CPR = ROWB / 16;
     constexpr int KS = D / 16, DB = D / 32;
     constexpr int LOFF = 4 * TILEB;  // LDS: T0[2] | T1[2] | L[2][64] | D[2][64] (floats; MODE 0 only)
@@ -416,11 +416,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : NWQ * 64, 2) void bwd_mfma16_kern
                     constexpr bool MASKED = decltype(masked_)::value;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        f32x4 lv = {Lown, Lown, Lown, Lown}, dv = {Down, Down, Down, Down};
-                        if (MODE == 0) {  // L and D of the four swept query rows 8g + 4h .. + 3
-                            lv = *(LDS_PTR(f32x4))(lds + LOFF + (cur * BS + kb * 32 + 8 * g + 4 * h) * 4);
-                            dv = *(LDS_PTR(f32x4))(lds + LOFF + (2 * BS + cur * BS + kb * 32 + 8 * g + 4 * h) * 4);
-                        }
+                        const f32x4 dv = {Down, Down, Down, Down};  // this path is the query owner's: D is per lane
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int r = 4 * g + j;
