@@ -65,12 +65,11 @@ int pick_variant(const Fa2Problem &p) {
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
         if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
         if (wg256 < 512) return FA2_VARIANT_MFMA16D_W4;
-        // 8-wave tiles.  MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop) measured against
-        // MFMA16D on MI355X: non-causal +4.4 % (d = 128, N = 4096), +4.8 % (N = 8192), +3 % (N = 1024), +9 % (d = 64);
-        // causal d = 64 +3 %, causal d = 128 -2..-4 % (the north-star shape stays on MFMA16D).
-        // (with the odd steady iteration on the hand-ordered path: causal d = 128 on par at N = 4096, +2 % at 8192,
-        // -2 % at 2048 -- the diagonal iterations still take the general path there)
-        return (p.causal && p.d == 128 && p.N < 8192) ? FA2_VARIANT_MFMA16D : FA2_VARIANT_MFMA16H;
+        // 8-wave tiles: MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop).  Against MFMA16D on
+        // MI355X (benchmarks/lottery.py, alternating order): non-causal +4.4 % (d = 128, N = 4096), +3.4 % (N = 8192),
+        // +9 % (d = 64); causal, once its causal kernels got a translation unit of their own: +4.1 % at the north-star
+        // shape (N = 4096), +4 % (N = 2048), +2.6 % (N = 8192), +2.5 % (N = 16384), +2.4 % (d = 64).
+        return FA2_VARIANT_MFMA16H;
     }
     if (fa2_mfma8_supports(p)) {
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
@@ -142,6 +141,10 @@ Fa2Problem make_problem(const void *Q, const void *K, const void *V, void *O, vo
     return p;
 }
 }  // namespace
+
+int fa2_launch_mfma16h(const Fa2Problem &p, int waves) {
+    return p.causal ? fa2_launch_mfma16h_causal(p, waves) : fa2_launch_mfma16h_noncausal(p, waves);
+}
 
 void fa2_set_error(const char *fmt, ...) {
     va_list ap;

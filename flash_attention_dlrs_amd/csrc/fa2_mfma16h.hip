@@ -8,6 +8,10 @@
 // Arithmetic, layouts and the tail / causal-diagonal path are those of fa2_mfma16d.hip (variant "mfma16h").
 #include "fa2_common.h"
 
+#ifndef FA2_H_ENTRY
+#define FA2_H_ENTRY fa2_launch_mfma16h
+#endif
+
 #ifdef FA2_STAMPS
 // Diagnostic build only (make stamps): per-phase s_memtime sums of workgroup 0, [wave][slot]; slot 15 = trips.
 __device__ unsigned long long fa2_stamp_buf[8][16];
@@ -650,10 +654,16 @@ template <typename T, int D, int NW> int launch_t(const Fa2Problem &p, const Dma
         }
         hipLaunchKernelGGL(kern, grid, block, smem, p.stream, a);
     };
-    if (p.causal)
-        launch(fa2_fwd_mfma16h_kernel<T, D, NW, true>);
-    else
-        launch(fa2_fwd_mfma16h_kernel<T, D, NW, false>);
+    // FA2_H_INST selects which instantiations this translation unit carries (1 = causal, 2 = non-causal, unset = both).
+    // The causal and the non-causal kernels are compiled in SEPARATE translation units (fa2_mfma16h_c.hip / _n.hip):
+    // co-compiled instantiations perturb each other's code generation (cdna_hip_programming.md rule 19) -- alone in
+    // its TU the causal kernel runs 3 % (N = 4096) to 6 % (N = 2048) faster, same source, same flags.
+#if !defined(FA2_H_INST) || FA2_H_INST == 1
+    if (p.causal) launch(fa2_fwd_mfma16h_kernel<T, D, NW, true>);
+#endif
+#if !defined(FA2_H_INST) || FA2_H_INST == 2
+    if (!p.causal) launch(fa2_fwd_mfma16h_kernel<T, D, NW, false>);
+#endif
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fa2_set_error("mfma16h kernel launch failed: %s", hipGetErrorString(e));
@@ -669,7 +679,7 @@ template <typename T> int launch_d(const Fa2Problem &p, const DmaArgs &a, int wa
 
 }  // namespace
 
-int fa2_launch_mfma16h(const Fa2Problem &p, int waves) {
+int FA2_H_ENTRY(const Fa2Problem &p, int waves) {
     const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31) &&
                         (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
     if (!fa2_mfma16_supports(p) || !fits32) {
