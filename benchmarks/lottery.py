@@ -19,7 +19,7 @@ cfg, variants, paths = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]  # ever
 c = CONFIGS[cfg]
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
-Q, K, V = (torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
+Q, K, V = ((torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev) * (0.5 if c["dtype"] == "fp8" else 1.0)).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
 O = torch.empty_like(Q)
 L = torch.empty(c["B"], c["H"], c["N"], 1, dtype=Q.dtype, device=dev)
 i64p, vp = ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p
@@ -32,7 +32,7 @@ for p in paths:
     l.fa2_fwd_variant.argtypes = [vp] * 5 + [i64p] * 5 + [ctypes.c_int32] * 6 + [ctypes.c_float, vp, ctypes.c_int32]
     for v in variants:
         libs.append((os.path.basename(p) + ":" + v, (l, v)))
-dt = {"bf16": 2, "fp16": 1}[c["dtype"]]
+dt = {"bf16": 2, "fp16": 1, "fp8": 4}[c["dtype"]]
 stream = torch.cuda.current_stream(dev).cuda_stream
 
 
