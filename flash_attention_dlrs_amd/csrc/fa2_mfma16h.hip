@@ -28,6 +28,7 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -41,11 +42,17 @@ template <> struct Mma<__bf16> {
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
 };
 template <> struct Mma<_Float16> {
     using frag = f16x8;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
 
@@ -127,6 +134,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
     // and Q rows are already in flight while this job's O leaves.  4-wave build (two workgroups per CU, LDS is the
     // limit): the slices alias the K/V buffers and the next job's loads start after the epilogue.
     constexpr bool EPI_SEP = NW == 8;
+#ifndef FA2_H_MSUM
+#define FA2_H_MSUM 0  // 1: steady-state row sums on the matrix pipe (16x16x32 with a 0/1 operand) instead of v_add_f32:
+                      // correct (parity suite green), measured -1 % (sums in the QK phase) to -2.5 % (in the P.V phase) on c3
+#endif
+#ifndef FA2_H_MSUM_QK
+#define FA2_H_MSUM_QK 6    // QK sub-step that carries the row-sum MFMA of P's first half (-1: both in the P.V phase)
+#endif
+#ifndef FA2_H_MSUM_PV1
+#define FA2_H_MSUM_PV1 (KS - 1)  // P.V sub-step that carries the one of the second half
+#endif
 #ifndef FA2_STAGGER
 #define FA2_STAGGER 0
 #endif
@@ -234,6 +251,23 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
 
     f32x16 o[DB];
     float m = -INFINITY, lsum = 0.0f;
+#if FA2_H_MSUM
+    // Row sums of the steady state come from the matrix pipe: one v_mfma_f32_16x16x32 per 16-key P fragment with a
+    // constant 0/1 A operand instead of 16 v_add_f32 per block step (the QK phase is VALU-issue bound, section 5 of
+    // DESIGN.md).  The P^T fragment of the 32x32x16 product (lane = query lane & 31, keys 8 (lane >> 5) + j) read as
+    // a 16x16x32 B operand is column n = lane & 15, k group g = lane >> 4: groups 0 / 2 are the two key halves of
+    // query n, groups 1 / 3 those of query n + 16.  A row m sums groups {0, 2} for m = 0, 8 and {1, 3} for m = 4, 12,
+    // so that register 0 of the result (row 4 (lane >> 4), column lane & 15) is the complete 16-key sum of the
+    // lane's OWN query in all 64 lanes.  The sum is over P as rounded to the I/O dtype -- the values P.V consumes.
+    f32x4 lacc = {0.0f, 0.0f, 0.0f, 0.0f};
+    frag ones;
+    {
+        const int mm = lane & 15, gg = lane >> 4;
+        const bool on = ((mm & 7) == 0 && (gg & 1) == 0) || ((mm & 7) == 4 && (gg & 1) == 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = on ? (T)1.0f : (T)0.0f;
+    }
+#endif
     const float c = a.c_log2e;
     // Rescale threshold in log2 units: P may reach 2^kThr before the running max is raised.  bf16 P has the
     // fp32 exponent range (24 leaves 2^24 * N far below fp32 overflow in l and O); f16 P must stay below 65504.
@@ -295,6 +329,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
                 }
             asm volatile("s_nop 7" ::: "memory");
             lsum *= coeff;
+#if FA2_H_MSUM
+            lacc[0] *= coeff;
+#endif
         }
     };
     auto pv = [&](frag (&pf)[2], int voff) {  // voff = buffer base + half * 32 rows
@@ -337,6 +374,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
         m = -INFINITY;
         lsum = 0.0f;
+#if FA2_H_MSUM
+        lacc[0] = lacc[1] = lacc[2] = lacc[3] = 0.0f;
+#endif
 
         f32x16 sA, sB;
         float coeffA = 1.0f, coeffB = 1.0f;
@@ -388,8 +428,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
 #pragma unroll
             for (int e = 0; e < EPK; ++e) {
                 const int r = g * EPK + e;
+#if !FA2_H_MSUM
                 if (e & 1) rs1 += sCur[r];
                 else rs0 += sCur[r];
+#endif
                 pf[r >> 3][r & 7] = (T)sCur[r];
             }
         };
@@ -421,6 +463,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
                 if (ks + 1 < KS) stageF(sCur, ks + 1);
                 stageE(sCur, ks);
                 if (ks >= 1) stageAC(sCur, ks - 1);
+#if FA2_H_MSUM
+                // the first 16 keys of P_j are complete after sub-step KS/2: their row sum rides in this (VALU-bound)
+                // phase, where the matrix pipe has idle cycles; the second 16 keys follow in the P.V phase
+                if (FA2_H_MSUM_QK >= 0 && ks == (FA2_H_MSUM_QK < KS ? FA2_H_MSUM_QK : KS - 1)) lacc = M::mfma16(ones, pf[0], lacc);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -435,9 +482,15 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             for (int idx = 0; idx < KS; ++idx) {
                 if (idx == 0) {
                     stageAC(sCur, KS - 1);
+#if !FA2_H_MSUM
                     lsum += rs0 + rs1;
+#endif
                 }
                 o[idx % DB] = M::mfma(vf[idx % R], pf[idx / DB], o[idx % DB]);
+#if FA2_H_MSUM
+                if (FA2_H_MSUM_QK < 0 && idx == DB - 1) lacc = M::mfma16(ones, pf[0], lacc);
+                if (idx == FA2_H_MSUM_PV1) lacc = M::mfma16(ones, pf[1], lacc);
+#endif
                 if (idx < R) vf[idx] = read_v(VIMM, idx + R);
                 else if (PREF_OUT) kf[idx - R] = read_k(KPREF, idx - R);
                 if (DMA_T >= 0 && idx < 2 * PPW) {
@@ -582,7 +635,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
         // from the accumulators that is 16 eight-byte stores per lane, each instruction touching 32 rows.  Instead the
         // wave's 32 x D tile goes through its own 32*ROWB-byte LDS slice and leaves as whole rows: ROWB/16 lanes x
         // 16 bytes per row, 1 KiB contiguous per store instruction.
+#if FA2_H_MSUM
+        const float l = half_swap_sum(lsum) + lacc[0];
+#else
         const float l = half_swap_sum(lsum);
+#endif
         const float inv = 1.0f / l;
         {
             const int ebase = EPI0 + wave * 32 * ROWB;
