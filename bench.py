@@ -49,8 +49,8 @@ CONFIGS = {  # BASELINE.json "configs"
 }
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "fp8": torch.float8_e4m3fn}
 # Dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (TFLOP/s)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3, "fp8": 5000.0}  # fp8: the block-scaled MX rate; the non-scaled
-# v_mfma_f32_32x32x16_fp8_fp8 used here runs at the bf16 rate (2500)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3, "fp8": 5000.0}  # fp8: the rate of v_mfma_f32_32x32x64_f8f6f4
+# (default fp8 kernel mfma8x); the 32x32x16 fp8 form of variant mfma8 runs at the bf16 rate (2500)
 
 
 def flops(c):

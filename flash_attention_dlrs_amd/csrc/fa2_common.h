@@ -25,11 +25,13 @@ int fa2_launch_mfma16p(const Fa2Problem &p, int waves, int opt);
 int fa2_launch_mfma16x(const Fa2Problem &p, int abl);
 int fa2_launch_mfma16d(const Fa2Problem &p, int waves);
 int fa2_launch_mfma8(const Fa2Problem &p, int waves);
+int fa2_launch_mfma8x(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16s(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16h(const Fa2Problem &p, int waves);  // dispatches to the two translation units below
 int fa2_launch_mfma16h_causal(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16h_noncausal(const Fa2Problem &p, int waves);
 bool fa2_mfma8_supports(const Fa2Problem &p);
+bool fa2_mfma8x_supports(const Fa2Problem &p);
 bool fa2_mfma16_supports(const Fa2Problem &p);
 bool fa2_mfma32_supports(const Fa2Problem &p);
 

@@ -124,7 +124,7 @@ def test_static_tile_table():
     assert q(256, 128, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32
     assert q(128, 32, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_GENERIC
     assert q(128, 64, _lib.FA2_DTYPE_F64)[0] == _lib.VARIANT_GENERIC
-    assert q(128, 128, _lib.FA2_DTYPE_F8E5M2)[0] in (_lib.VARIANT_MFMA8, _lib.VARIANT_MFMA8_W4)
+    assert q(128, 128, _lib.FA2_DTYPE_F8E5M2)[0] in (_lib.VARIANT_MFMA8X, _lib.VARIANT_MFMA8X_W4)
     assert q(128, 64, _lib.FA2_DTYPE_F8E4M3)[0] == _lib.VARIANT_GENERIC
     # supported N domain is a superset of the reference's (multiples of 16, autotune_configs.py:176-187)
     for N in (16, 48, 100, 4096):

@@ -252,8 +252,9 @@ def test_fp8_generic_vs_oracle(oracle, dtype, causal):
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("variant", ["mfma8", "mfma8_w4", "auto"])
-@pytest.mark.parametrize("shape", [(1, 2, 64, 128), (2, 2, 320, 128), (1, 1, 77, 128), (1, 8, 1024, 128)],
+@pytest.mark.parametrize("variant", ["mfma8", "mfma8_w4", "mfma8x", "mfma8x_w4", "auto"])
+@pytest.mark.parametrize("shape", [(1, 2, 64, 128), (2, 2, 320, 128), (1, 1, 77, 128), (1, 8, 1024, 128), (1, 3, 191, 128),
+                                   (3, 1, 513, 128), (1, 2, 2049, 128)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_fp8_mfma_kernel(oracle, dtype, causal, variant, shape):
     """fp8 on the matrix cores (BASELINE.json c5 family).  P is rounded to fp8 relative to the running max of ITS
