@@ -20,9 +20,14 @@
 // LDS images, DMA staging, causal tile pairs, launch order and epilogue are those of fa2_mfma8.hip.
 #include "fa2_common.h"
 
+#ifndef FA2_8X_MSUM
+#define FA2_8X_MSUM 1  // row sums by a 16x16x128 MFMA against a 0/1 operand instead of v_add_f32
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -37,6 +42,11 @@ template <bool E4M3> struct F8 {
         if constexpr (E4M3) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
         else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma_sum(i32x8 a, i32x8 b, f32x4 c) {  // 16x16x128
+        if constexpr (E4M3) return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0);
+    }
+    static constexpr int kOnes = E4M3 ? 0x38383838 : 0x3c3c3c3c;  // four fp8 1.0
     // two floats -> two fp8 (RTNE) into the low (hi = false) or high half of `old`
     template <bool HI> static __device__ __forceinline__ int cvt_pk(float x, float y, int old) {
         if constexpr (E4M3) return __builtin_amdgcn_cvt_pk_fp8_f32(x, y, old, HI);
@@ -190,7 +200,25 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
     }
 
     f32x16 o[DB];
-    float m = -INFINITY, lsum = 0.0f;
+    float m = -INFINITY;
+#if !FA2_8X_MSUM
+    float lsum = 0.0f;
+#else
+    // Row sums on the matrix pipe: one v_mfma_f32_16x16x128_f8f6f4 per 64-key unit with a constant 0/1 A operand
+    // instead of 32 v_add_f32 (this kernel is VALU-issue bound).  The P^T fragment (lane = query lane & 31, 32 keys of
+    // half lane >> 5) read as a 16x16x128 B operand is column n = lane & 15, k group g = lane >> 4: groups 0 / 2 are
+    // the two key halves of query n, groups 1 / 3 those of query n + 16.  A row m sums groups {0, 2} for m = 0, 8 and
+    // {1, 3} for m = 4, 12, so register 0 of the result (row 4 (lane >> 4), column lane & 15) is the complete 64-key
+    // sum of the lane's OWN query in all 64 lanes.  The sum is over P as rounded to fp8 -- the values P.V consumes.
+    f32x4 lacc = {0.0f, 0.0f, 0.0f, 0.0f};
+    i32x8 ones;
+    {
+        const int mm = lane & 15, gg = lane >> 4;
+        const bool on = ((mm & 7) == 0 && (gg & 1) == 0) || ((mm & 7) == 4 && (gg & 1) == 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = on ? M::kOnes : 0;
+    }
+#endif
     const float c = a.c_log2e;
     constexpr float kThr = 6.0f;  // P <= 64 before the running max is raised (e4m3 tops out at 448)
 
@@ -235,10 +263,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
         }
         return fire;
     };
-    // P = exp2(S*c - m), row sum of the unrounded P, P -> fp8 RTNE (kernels.py:94-98); dword 4b + 2ss + e of pf =
+    // P = exp2(S*c - m), P -> fp8 RTNE (kernels.py:94-98), row sum (of the rounded P with FA2_8X_MSUM, else unrounded); dword 4b + 2ss + e of pf =
     // registers 8ss + 4e .. +3 of block b
     auto finish = [&](f32x16 &s0, f32x16 &s1, i32x8 &pf) __attribute__((always_inline)) {
+#if !FA2_8X_MSUM
         float rs0 = 0.0f, rs1 = 0.0f;
+#endif
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             f32x16 &s = b ? s1 : s0;
@@ -246,8 +276,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -m));
+#if !FA2_8X_MSUM
                 if (r & 1) rs1 += p[r];
                 else rs0 += p[r];
+#endif
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -256,7 +288,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
                 pf[4 * b + q] = w;
             }
         }
+#if FA2_8X_MSUM
+        lacc = M::mfma_sum(ones, pf, lacc);
+#else
         lsum += rs0 + rs1;
+#endif
     };
     auto rescale = [&](bool fire, float coeff) __attribute__((always_inline)) {
         if (fire) {
@@ -270,7 +306,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
                     o[db][r] = x;
                 }
             asm volatile("s_nop 7" ::: "memory");
+#if FA2_8X_MSUM
+            lacc[0] *= coeff;
+#else
             lsum *= coeff;
+#endif
         }
     };
     auto pv = [&](const i32x8 &pf, int voff) __attribute__((always_inline)) {  // voff = V buffer base; 64 keys
@@ -314,7 +354,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
         m = -INFINITY;
+#if FA2_8X_MSUM
+        lacc[0] = lacc[1] = lacc[2] = lacc[3] = 0.0f;
+#else
         lsum = 0.0f;
+#endif
 
         dma_k(0, 0);
         dma_v(0, 0);
@@ -384,7 +428,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
         // ---- epilogue: O = O / l and L = m + log2 l, both rounded to fp8 (kernels.py:105-108).  Lane (i, h) owns
         // row q0+i, columns 32db + 8g + 4h .. +3 (four fp8 = one dword); the wave's 32 x 128-byte tile goes through
         // its own 4-KiB slice of the idle K/V buffers and leaves as whole rows (see fa2_mfma16d.hip).
+#if FA2_8X_MSUM
+        const float l = lacc[0];
+#else
         const float l = half_swap_sum(lsum);
+#endif
         const float inv = 1.0f / l;
         {
             const int ebase = wave * 32 * ROWB;
