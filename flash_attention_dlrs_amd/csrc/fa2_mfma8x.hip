@@ -18,6 +18,13 @@
 //     fa2_mfma8.hip) concatenated in the same (b, r) order.
 //   * K tiles are aligned with V tiles (keys 64t .. 64t+63), no 32-key offset.
 // LDS images, DMA staging, causal tile pairs, launch order and epilogue are those of fa2_mfma8.hip.
+// rocprofv3 on the c5 per-GPU shape (profiles/r01/c5_mfma8x_rocprof.json): 2.23 GHz, matrix pipe busy 49 % -- unlike the
+// bf16 kernels this one is not at the power limit but VALU-issue bound (32 fma + 32 exp2 + 16 max3 + 16 cvt per 9 MFMAs).
+// Measured and dropped: (1) staging two tiles ahead through rings of three K / V buffers with a counted vmcnt: -3 %,
+// the kernel is not waiting for its DMA; (2) running the P.V of unit t one iteration late so that all nine MFMAs are
+// independent of the softmax in flight (two-deep rescale queue, three V buffers; correct, parity green): -10 % with
+// the compiler's schedule, which clusters the MFMAs instead of spreading them through the exp2 stream -- it needs the
+// hand-ordered sub-steps of fa2_mfma16h.hip to pay.
 #include "fa2_common.h"
 
 #ifndef FA2_8X_MSUM
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
         }
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);  // one v_max3_f32 per pair (+3 %)
         mx = half_swap_max(mx) * c;
         const bool fire = !__all(mx - m <= kThr);
         coeff = 1.0f;
