@@ -31,6 +31,10 @@
 #define FA2_8X_MSUM 1  // row sums by a 16x16x128 MFMA against a 0/1 operand instead of v_add_f32
 #endif
 
+#ifndef FA2_8X_ABL
+#define FA2_8X_ABL 0  // 1..5: timing-only ablations (WRONG results), see DESIGN.md section 5
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -258,8 +262,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
             }
         }
         float mx = fmaxf(s0[0], s1[0]);
+#if FA2_8X_ABL != 3   /* 3: no running max */
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);  // one v_max3_f32 per pair (+3 %)
+#endif
         mx = half_swap_max(mx) * c;
         const bool fire = !__all(mx - m <= kThr);
         coeff = 1.0f;
@@ -282,7 +288,13 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if FA2_8X_ABL == 1   /* no exp2 */
+                p[r] = __builtin_fmaf(s[r], c, -m);
+#elif FA2_8X_ABL == 2 /* no fma, no exp2 */
+                p[r] = s[r];
+#else
                 p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -m));
+#endif
 #if !FA2_8X_MSUM
                 if (r & 1) rs1 += p[r];
                 else rs0 += p[r];
@@ -397,10 +409,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
             qk(n0, knext);
             qk(n1, knext + 32 * ROWB);
             finish(c0, c1, pf);
+#if FA2_8X_ABL != 5   /* 5: no P.V */
             pv(pf, vcur);
+#else
+            asm volatile("" ::"v"(pf));
+#endif
             fire = partial(n0, n1, t + 1, coeff, false);
             dma_wait();
+#if FA2_8X_ABL != 4   /* 4: no barrier in the steady loop */
             __syncthreads();
+#endif
         };
         auto guarded = [&](int t, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) __attribute__((always_inline)) {
             if (t + 1 < nt) {
