@@ -18,7 +18,7 @@
 //     fa2_mfma8.hip) concatenated in the same (b, r) order.
 //   * K tiles are aligned with V tiles (keys 64t .. 64t+63), no 32-key offset.
 // LDS images, DMA staging, causal tile pairs, launch order and epilogue are those of fa2_mfma8.hip.
-// rocprofv3 on the c5 per-GPU shape (profiles/r01/c5_mfma8x_rocprof.json): 2.23 GHz, matrix pipe busy 49 % -- unlike the
+// rocprofv3 on the c5 per-GPU shape (profiles/r01/c5_per_gpu_mfma8x_rocprof.json): 2.23 GHz, matrix pipe busy 49 % -- unlike the
 // bf16 kernels this one is not at the power limit but VALU-issue bound (32 fma + 32 exp2 + 16 max3 + 16 cvt per 9 MFMAs).
 // Measured and dropped: (1) staging two tiles ahead through rings of three K / V buffers with a counted vmcnt: -3 %,
 // the kernel is not waiting for its DMA; (2) running the P.V of unit t one iteration late so that all nine MFMAs are
