@@ -144,10 +144,6 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
 #ifndef FA2_H_MSUM_PV1
 #define FA2_H_MSUM_PV1 (KS - 1)  // P.V sub-step that carries the one of the second half
 #endif
-#ifndef FA2_STAGGER
-#define FA2_STAGGER 0
-#endif
-    constexpr bool STAGGER = FA2_STAGGER != 0;
     constexpr int EPI0 = EPI_SEP ? 4 * TILEB : 0;
     constexpr int RPI = 64 / CPR;                  // rows per epilogue store instruction (4 at d = 128, 8 at d = 64)
     constexpr int NST = 32 / RPI + 1;              // store instructions per wave and job: O rows + L
@@ -514,11 +510,6 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
                 m = m_new;
             }
         };
-        // The two halves of the workgroup run the four phases of an iteration ONE PHASE APART (waves w and w + NW/2
-        // share a SIMD): group X does QK.PV.QK.PV, group Y does PV.QK.PV.QK with its first PV finishing the previous
-        // iteration's second block -- so a SIMD always pairs a VALU-bound QK phase with an MFMA-paced PV phase instead
-        // of running two of a kind against each other (in-kernel stamps: lockstep waves took the SUM of their phases).
-        const bool groupY = STAGGER && wave >= NW / 2;
         auto iterX = [&](auto par_, int t) __attribute__((always_inline)) {  // par_ = t & 1
             constexpr int PAR = decltype(par_)::value;
             constexpr int KCUR = (PAR ^ 1) * TILEB;  // K unit t+1: rows 0..31 = block 2t+1, rows 32..63 = block 2t+2
@@ -541,45 +532,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
             dma_wait();  // this wave's pieces of (K unit t+2, V tile t+1) have landed; the barrier publishes them
             __syncthreads();
         };
-        auto iterY = [&](auto par_, auto first_, int t) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par_)::value;
-            constexpr int KCUR = (PAR ^ 1) * TILEB, VCUR = PAR * TILEB, VPREV = (PAR ^ 1) * TILEB;
-            if (decltype(first_)::value) {
-                dma_k(t + 2, PAR);
-                dma_v(t + 1, PAR ^ 1);
-            } else {
-                pv_phase(IC<VPREV + 32 * ROWB>{}, IC<KCUR>{}, t, PAR ^ 1, sB, sA, fireA, coeffA);
-            }
-            qk_phase(IC<KCUR>{}, IC<VCUR>{}, IC<1>{}, sA, sB, fireA, coeffA);
-            pv_phase(IC<VCUR>{}, IC<KCUR + 32 * ROWB>{}, -1, 0, sA, sB, fireB, coeffB);
-            qk_phase(IC<KCUR + 32 * ROWB>{}, IC<VCUR + 32 * ROWB>{}, IC<1>{}, sB, sA, fireB, coeffB);
-            dma_wait();
-            __syncthreads();
-        };
         int t = 0;
-        if (!groupY) {
-            for (; t + 1 < t_steady; t += 2) {
-                iterX(IC<0>{}, t);
-                iterX(IC<1>{}, t + 1);
-            }
-            if (t < t_steady) {  // odd count: t is even here, one more hand-ordered iteration instead of the general path
-                iterX(IC<0>{}, t);  // (causal c3: -2.8 % -> parity with mfma16d; N = 8192 causal: -1.8 % -> +2.2 %)
-                ++t;
-            }
-            // (routing the diagonal / tail iterations through these phases too -- run-time offsets, HAS_NEXT / MASKED
-            // variants -- was built and is correct, but the extra phase bodies cost 77-152 spilled registers and 15 %)
-        } else if (t_steady >= 2) {
-#pragma unroll
-            for (int ks = 0; ks < R; ++ks) kf[ks] = read_k(TILEB, ks);  // K unit 1 rows 0..31 (iteration 0's first block)
-            iterY(IC<0>{}, IC<1>{}, 0);
-            iterY(IC<1>{}, IC<0>{}, 1);
-            for (t = 2; t + 1 < t_steady; t += 2) {
-                iterY(IC<0>{}, IC<0>{}, t);
-                iterY(IC<1>{}, IC<0>{}, t + 1);
-            }
-            // group Y's deferred P.V of the last steady block
-            pv_phase(IC<TILEB + 32 * ROWB>{}, IC<-1>{}, -1, 0, sB, sA, fireA, coeffA);
+        for (; t + 1 < t_steady; t += 2) {
+            iterX(IC<0>{}, t);
+            iterX(IC<1>{}, t + 1);
         }
+        if (t < t_steady) {  // odd count: t is even here, one more hand-ordered iteration instead of the general path
+            iterX(IC<0>{}, t);  // (causal c3: -2.8 % -> parity with mfma16d; N = 8192 causal: -1.8 % -> +2.2 %)
+            ++t;
+        }
+        // (routing the diagonal / tail iterations through these phases too -- run-time offsets, HAS_NEXT / MASKED
+        // variants -- was built and is correct, but the extra phase bodies cost 77-152 spilled registers and 15 %.
+        // Running waves NW/2.. one phase behind the others, QK against P.V on every SIMD, was emulated in a timing-only
+        // build: +3 %, and it needs a third V buffer -- DESIGN.md section 5.)
         for (; t < nt; ++t) {
             const bool more = t + 1 < nt;
             if (more) {
