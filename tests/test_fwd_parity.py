@@ -281,6 +281,61 @@ def test_fp8_mfma_kernel(oracle, dtype, causal, variant, shape):
     assert ((L - Lref).abs() <= ulp * Lref.abs() + 1e-3).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("variant", ["mfma8", "mfma8x", "mfma8x_w4"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp8_rescale_and_layouts(oracle, dtype, variant, causal):
+    """fp8 matrix kernels where the running max jumps late (keys grow in norm, one spiked key in the last unit: the
+    rescale of O and of the row sum -- kept in MFMA accumulators by mfma8x -- is taken after O is non-zero), with
+    (B, N, H, d)-strided Q/K/V views as the reference's wrappers may pass (src/test_kernels.py strided case).
+    Bars as in test_fp8_mfma_kernel, against the exact attention of the fp8 inputs."""
+    B, H, N, d = 2, 3, 448, 128
+    gen = torch.Generator().manual_seed(77)
+    Q, K, V = ((torch.randn(B, N, H, d, generator=gen) * 0.4) for _ in range(3))
+    K = K * torch.linspace(0.3, 1.6, N).view(1, N, 1, 1)
+    K[:, N - 3] = Q[:, 11] * 2.0  # row 11's maximum jumps in the final 64-key unit
+    Q, K, V = (t.to(dtype).transpose(1, 2) for t in (Q, K, V))  # (B, H, N, d) views of (B, N, H, d) storage
+    assert not Q.is_contiguous()
+    f = lambda t: t.float().contiguous().numpy()
+    O64, L64 = oracle.sdpa_f64(f(Q), f(K), f(V), causal=causal)
+    O, L = fa.flash_attention_forward(Q.to(DEV), K.to(DEV), V.to(DEV), DEV, causal=causal, variant=variant)
+    torch.cuda.synchronize()
+    O, L = O.cpu().float(), L.cpu().float()
+    ulp = 2.0 ** -3 if dtype == torch.float8_e4m3fn else 2.0 ** -2
+    ref = torch.from_numpy(O64).float()
+    rel = ((O - ref).abs() / ref.abs().clamp(min=0.05)).flatten()
+    assert torch.isfinite(O).all()
+    assert rel.median() <= ulp / 2 and rel.kthvalue(int(0.99 * rel.numel())).values <= 3 * ulp
+    Lref = torch.from_numpy(L64).float()
+    assert ((L - Lref).abs() <= ulp * Lref.abs() + 1e-3).all()
+
+
+def test_fp8_c5_head_shard_properties():
+    """BASELINE.json configs[4] (B16 H64 N16384 d128 fp8, head/batch-sharded over 8 GPUs) at full N on a slice of one
+    GPU's shard, through size-independent properties: run-to-run bit equality, bit-identical head indexing (head
+    shards run separately == the full run), V = 1 => O = 1 exactly, key permutation invariance within fp8 rounding."""
+    dtype, B, H, N, d = torch.float8_e4m3fn, 1, 8, 16384, 128
+    torch.manual_seed(42)
+    Q, K, V = ((torch.randn(B, H, N, d, device=DEV) * 0.5).to(dtype) for _ in range(3))
+    assert _lib.query_tile(N, d, _lib.FA2_DTYPE_F8E4M3, False)[0] == _lib.VARIANT_MFMA8X
+    O, L = fa.flash_attention_forward(Q, K, V, DEV)
+    O2, L2 = fa.flash_attention_forward(Q, K, V, DEV)
+    assert torch.equal(O.view(torch.uint8), O2.view(torch.uint8)) and torch.equal(L.view(torch.uint8), L2.view(torch.uint8))
+    parts = [fa.flash_attention_forward(Q[:, h0:h0 + 2].contiguous(), K[:, h0:h0 + 2].contiguous(),
+                                        V[:, h0:h0 + 2].contiguous(), DEV)[0] for h0 in range(0, H, 2)]
+    assert torch.equal(torch.cat(parts, dim=1).view(torch.uint8), O.view(torch.uint8))
+    O1, _ = fa.flash_attention_forward(Q, K, torch.ones(B, H, N, d, device=DEV).to(dtype), DEV)
+    assert (O1.float() == 1).all()
+    assert torch.isfinite(O.float()).all() and torch.isfinite(L.float()).all()
+    # one (b, h) against the exact attention of the fp8 inputs (fp64 on the GPU), statistical bars of the fp8 tests
+    S = Q[0, 0].double() @ K[0, 0].double().T
+    ref = (torch.softmax(S, dim=-1) @ V[0, 0].double()).float()
+    rel = ((O[0, 0].float() - ref).abs() / ref.abs().clamp(min=0.05)).flatten()
+    assert rel.median() <= 2.0 ** -4 and rel.kthvalue(int(0.99 * rel.numel())).values <= 3 * 2.0 ** -3
+    lse2 = (torch.logsumexp(S, dim=-1) * math.log2(math.e)).float()
+    assert ((L[0, 0].float().flatten() - lse2).abs() <= 2.0 ** -3 * lse2.abs() + 1e-3).all()
+
+
 @pytest.mark.parametrize("dtype,variant", [(torch.float32, "mfma32"), (torch.bfloat16, "mfma16"),
                                            (torch.bfloat16, "mfma16_w8"), (torch.float32, "generic"),
                                            (torch.bfloat16, "mfma16d"), (torch.bfloat16, "mfma16s"),
@@ -319,15 +374,17 @@ def test_no_out_of_bounds_writes_for_ragged_N():
     for dtype, variant, d in ((torch.float32, "mfma32", 64), (torch.bfloat16, "mfma16", 64),
                               (torch.bfloat16, "mfma16_w8", 64), (torch.float32, "generic", 64),
                               (torch.bfloat16, "mfma16d", 128), (torch.bfloat16, "mfma16s", 128),
-                              (torch.bfloat16, "mfma16h", 128), (torch.float16, "mfma16h_w4", 64)):
+                              (torch.bfloat16, "mfma16h", 128), (torch.float16, "mfma16h_w4", 64),
+                              (torch.float8_e4m3fn, "mfma8x", 128), (torch.float8_e5m2, "mfma8x_w4", 128),
+                              (torch.float8_e4m3fn, "mfma8", 128)):
         B, H, N = 1, 2, 77
         Q, K, V = (t.to(DEV) for t in _rand((B, H, N, d), dtype, seed=3))
-        arena = torch.full((3, B, H, N, d), 7.0, dtype=dtype, device=DEV)
-        arena_l = torch.full((3, B, H, N, 1), 7.0, dtype=dtype, device=DEV)
+        arena = torch.full((3, B, H, N, d), 7.0, device=DEV).to(dtype)  # 7 is exact in every dtype here, fp8 included
+        arena_l = torch.full((3, B, H, N, 1), 7.0, device=DEV).to(dtype)
         O, L = arena[1], arena_l[1]
         _lib.fa2_fwd(Q, K, V, O, L, fa.convert_triton_dtype(dtype), variant=_lib.VARIANTS[variant])
         torch.cuda.synchronize()
-        assert (arena[0] == 7).all() and (arena[2] == 7).all() and (arena_l[0] == 7).all() and (arena_l[2] == 7).all()
+        assert all((t.float() == 7).all() for t in (arena[0], arena[2], arena_l[0], arena_l[2]))
         assert torch.isfinite(O.float()).all() and (O.float().abs() < 7).all()
 
 
