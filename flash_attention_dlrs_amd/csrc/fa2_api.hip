@@ -97,6 +97,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA8_W4: return fa2_launch_mfma8(p, 4);
     case FA2_VARIANT_MFMA8X: return fa2_launch_mfma8x(p, 8);
     case FA2_VARIANT_MFMA8X_W4: return fa2_launch_mfma8x(p, 4);
+    case FA2_VARIANT_MFMA8U: return fa2_launch_mfma8x(p, 12);
     case FA2_VARIANT_MFMA16D: return fa2_launch_mfma16d(p, 8);
     case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
     case FA2_VARIANT_MFMA16H: return fa2_launch_mfma16h(p, 8);
@@ -212,6 +213,7 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA8X: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8X_W4: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA8U: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16D: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16H: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;

@@ -116,8 +116,11 @@ __device__ __forceinline__ int swz_k(int row) { return (((row >> 1) & 1) << 2) |
 // V image: 32-byte unit u of row r at r*128 + ((u ^ f(r)) << 5).
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-template <bool E4M3, int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args a) {
+// WPS = waves per SIMD the register budget is cut for: 2 = the software-pipelined loop (S of unit t+1 under the softmax
+// of unit t); 3 = one unit at a time (S, softmax, P.V in sequence, <= 168 registers), three workgroups of four waves per
+// CU, the overlap left to the hardware's choice among three instruction streams (variant "mfma8u").
+template <bool E4M3, int NW, bool CAUSAL, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void fa2_fwd_mfma8x_kernel(const F8Args a) {
     using M = F8<E4M3>;
     constexpr int D = 128, BR = NW * 32;
     constexpr int ROWB = D;                        // one byte per element
@@ -379,75 +382,102 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
         lsum = 0.0f;
 #endif
 
-        dma_k(0, 0);
-        dma_v(0, 0);
-        dma_k(1, 1);
-        dma_wait();
-        __syncthreads();
-
-        f32x16 sA, sB, sC, sD;
-        float coeff = 1.0f;
-        bool fire = false;
-        i32x8 pf;
-        qk(sA, 0);  // unit 0 = K tile 0
-        qk(sB, 32 * ROWB);
-        fire = partial(sA, sB, 0, coeff, unit_masked(0));
-        __syncthreads();  // K tile 0 is overwritten by tile 2 in iteration 0
-
-        // iteration t: DMA of K tile t+2 / V tile t+1; S of unit t+1 (K tile t+1) under the softmax of unit t; P.V of
-        // unit t (V tile t); running max of unit t+1.  Steady iterations: units t and t+1 need no mask for this wave.
-        int n_free = N >> 6;  // leading units without any masked element
-        if (CAUSAL) n_free = ((q0 + 1) >> 6) < n_free ? ((q0 + 1) >> 6) : n_free;
-        int t_steady = n_free - 1;
-        t_steady = t_steady < 0 ? 0 : (t_steady > nt - 1 ? nt - 1 : t_steady);
-
-        auto steady = [&](int t, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) __attribute__((always_inline)) {
-            dma_k(t + 2, t & 1);
-            dma_v(t + 1, (t + 1) & 1);
-            const int knext = ((t + 1) & 1) * TILEB, vcur = (t & 1) * TILEB;
-            rescale(fire, coeff);
-            qk(n0, knext);
-            qk(n1, knext + 32 * ROWB);
-            finish(c0, c1, pf);
-#if FA2_8X_ABL != 5   /* 5: no P.V */
-            pv(pf, vcur);
-#else
-            asm volatile("" ::"v"(pf));
-#endif
-            fire = partial(n0, n1, t + 1, coeff, false);
+        if constexpr (WPS == 3) {
+            dma_k(0, 0);
+            dma_v(0, 0);
             dma_wait();
-#if FA2_8X_ABL != 4   /* 4: no barrier in the steady loop */
             __syncthreads();
-#endif
-        };
-        auto guarded = [&](int t, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) __attribute__((always_inline)) {
-            if (t + 1 < nt) {
+            f32x16 sA, sB;
+            float coeff = 1.0f;
+            i32x8 pf;
+            for (int t = 0; t < nt; ++t) {  // K tile t and V tile t both live in buffer t & 1
+                if (t + 1 < nt) {
+                    dma_k(t + 1, (t + 1) & 1);
+                    dma_v(t + 1, (t + 1) & 1);
+                }
+                if (t < nu) {
+                    const int cur = (t & 1) * TILEB;
+                    qk(sA, cur);
+                    qk(sB, cur + 32 * ROWB);
+                    const bool fire = partial(sA, sB, t, coeff, unit_masked(t));
+                    rescale(fire, coeff);
+                    finish(sA, sB, pf);
+                    pv(pf, cur);
+                }
+                dma_wait();
+                __syncthreads();
+            }
+        } else {
+            dma_k(0, 0);
+            dma_v(0, 0);
+            dma_k(1, 1);
+            dma_wait();
+            __syncthreads();
+
+            f32x16 sA, sB, sC, sD;
+            float coeff = 1.0f;
+            bool fire = false;
+            i32x8 pf;
+            qk(sA, 0);  // unit 0 = K tile 0
+            qk(sB, 32 * ROWB);
+            fire = partial(sA, sB, 0, coeff, unit_masked(0));
+            __syncthreads();  // K tile 0 is overwritten by tile 2 in iteration 0
+
+            // iteration t: DMA of K tile t+2 / V tile t+1; S of unit t+1 (K tile t+1) under the softmax of unit t; P.V of
+            // unit t (V tile t); running max of unit t+1.  Steady iterations: units t and t+1 need no mask for this wave.
+            int n_free = N >> 6;  // leading units without any masked element
+            if (CAUSAL) n_free = ((q0 + 1) >> 6) < n_free ? ((q0 + 1) >> 6) : n_free;
+            int t_steady = n_free - 1;
+            t_steady = t_steady < 0 ? 0 : (t_steady > nt - 1 ? nt - 1 : t_steady);
+
+            auto steady = [&](int t, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) __attribute__((always_inline)) {
                 dma_k(t + 2, t & 1);
                 dma_v(t + 1, (t + 1) & 1);
-            }
-            const int knext = ((t + 1) & 1) * TILEB, vcur = (t & 1) * TILEB;
-            const bool cur = t < nu, nxt = t + 1 < nu;
-            if (cur) rescale(fire, coeff);
-            if (nxt) {
+                const int knext = ((t + 1) & 1) * TILEB, vcur = (t & 1) * TILEB;
+                rescale(fire, coeff);
                 qk(n0, knext);
                 qk(n1, knext + 32 * ROWB);
-            }
-            if (cur) {
                 finish(c0, c1, pf);
+    #if FA2_8X_ABL != 5   /* 5: no P.V */
                 pv(pf, vcur);
+    #else
+                asm volatile("" ::"v"(pf));
+    #endif
+                fire = partial(n0, n1, t + 1, coeff, false);
+                dma_wait();
+    #if FA2_8X_ABL != 4   /* 4: no barrier in the steady loop */
+                __syncthreads();
+    #endif
+            };
+            auto guarded = [&](int t, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) __attribute__((always_inline)) {
+                if (t + 1 < nt) {
+                    dma_k(t + 2, t & 1);
+                    dma_v(t + 1, (t + 1) & 1);
+                }
+                const int knext = ((t + 1) & 1) * TILEB, vcur = (t & 1) * TILEB;
+                const bool cur = t < nu, nxt = t + 1 < nu;
+                if (cur) rescale(fire, coeff);
+                if (nxt) {
+                    qk(n0, knext);
+                    qk(n1, knext + 32 * ROWB);
+                }
+                if (cur) {
+                    finish(c0, c1, pf);
+                    pv(pf, vcur);
+                }
+                if (nxt) fire = partial(n0, n1, t + 1, coeff, unit_masked(t + 1));
+                dma_wait();
+                __syncthreads();
+            };
+            int t = 0;
+            for (; t + 1 < t_steady; t += 2) {
+                steady(t, sA, sB, sC, sD);
+                steady(t + 1, sC, sD, sA, sB);
             }
-            if (nxt) fire = partial(n0, n1, t + 1, coeff, unit_masked(t + 1));
-            dma_wait();
-            __syncthreads();
-        };
-        int t = 0;
-        for (; t + 1 < t_steady; t += 2) {
-            steady(t, sA, sB, sC, sD);
-            steady(t + 1, sC, sD, sA, sB);
-        }
-        for (; t < nt; t += 2) {  // t is even: unit t sits in (sA, sB)
-            guarded(t, sA, sB, sC, sD);
-            if (t + 1 < nt) guarded(t + 1, sC, sD, sA, sB);
+            for (; t < nt; t += 2) {  // t is even: unit t sits in (sA, sB)
+                guarded(t, sA, sB, sC, sD);
+                if (t + 1 < nt) guarded(t + 1, sC, sD, sA, sB);
+            }
         }
 
         // ---- epilogue: O = O / l and L = m + log2 l, both rounded to fp8 (kernels.py:105-108).  Lane (i, h) owns
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma8x_kernel(const F8Args
     }  // pass
 }
 
-template <bool E4M3, int NW> int launch_t(const Fa2Problem &p, const F8Args &a) {
+template <bool E4M3, int NW, int WPS = 2> int launch_t(const Fa2Problem &p, const F8Args &a) {
     constexpr int BR = NW * 32;
     const int nq = (p.N + BR - 1) / BR;
     const long long nblk = (long long)(p.causal ? (nq + 1) / 2 : nq) * p.B * p.H;
@@ -498,9 +528,9 @@ template <bool E4M3, int NW> int launch_t(const Fa2Problem &p, const F8Args &a) 
     const dim3 grid((unsigned)nblk), block(NW * 64);
     constexpr size_t smem = 4 * 64 * 128;
     if (p.causal)
-        hipLaunchKernelGGL((fa2_fwd_mfma8x_kernel<E4M3, NW, true>), grid, block, smem, p.stream, a);
+        hipLaunchKernelGGL((fa2_fwd_mfma8x_kernel<E4M3, NW, true, WPS>), grid, block, smem, p.stream, a);
     else
-        hipLaunchKernelGGL((fa2_fwd_mfma8x_kernel<E4M3, NW, false>), grid, block, smem, p.stream, a);
+        hipLaunchKernelGGL((fa2_fwd_mfma8x_kernel<E4M3, NW, false, WPS>), grid, block, smem, p.stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fa2_set_error("mfma8x kernel launch failed: %s", hipGetErrorString(e));
@@ -545,5 +575,6 @@ int fa2_launch_mfma8x(const Fa2Problem &p, int waves) {
     }
     const bool e4 = p.dtype == FA2_DTYPE_F8E4M3;
     if (waves == 8) return e4 ? launch_t<true, 8>(p, a) : launch_t<false, 8>(p, a);
+    if (waves == 12) return e4 ? launch_t<true, 4, 3>(p, a) : launch_t<false, 4, 3>(p, a);  // "mfma8u"
     return e4 ? launch_t<true, 4>(p, a) : launch_t<false, 4>(p, a);
 }

@@ -252,7 +252,7 @@ def test_fp8_generic_vs_oracle(oracle, dtype, causal):
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("variant", ["mfma8", "mfma8_w4", "mfma8x", "mfma8x_w4", "auto"])
+@pytest.mark.parametrize("variant", ["mfma8", "mfma8_w4", "mfma8x", "mfma8x_w4", "mfma8u", "auto"])
 @pytest.mark.parametrize("shape", [(1, 2, 64, 128), (2, 2, 320, 128), (1, 1, 77, 128), (1, 8, 1024, 128), (1, 3, 191, 128),
                                    (3, 1, 513, 128), (1, 2, 2049, 128)],
                          ids=lambda s: "x".join(map(str, s)))
@@ -282,7 +282,7 @@ def test_fp8_mfma_kernel(oracle, dtype, causal, variant, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
-@pytest.mark.parametrize("variant", ["mfma8", "mfma8x", "mfma8x_w4"])
+@pytest.mark.parametrize("variant", ["mfma8", "mfma8x", "mfma8x_w4", "mfma8u"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_fp8_rescale_and_layouts(oracle, dtype, variant, causal):
     """fp8 matrix kernels where the running max jumps late (keys grow in norm, one spiked key in the last unit: the
