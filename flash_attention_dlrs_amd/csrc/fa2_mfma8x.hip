@@ -35,6 +35,18 @@
 #define FA2_8X_ABL 0  // 1..5: timing-only ablations (WRONG results), see DESIGN.md section 5
 #endif
 
+#ifdef FA2_STAMPS
+// Diagnostic build only: s_memtime sums of workgroup 0 per wave -- [0] iteration body, [1] DMA wait, [2] barrier wait,
+// [15] iterations (steady loop only).  benchmarks/stamps.py <config> mfma8x.
+__device__ unsigned long long fa2_stamp_buf[8][16];
+extern "C" int fa2_debug_read_stamps(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fa2_stamp_buf), sizeof(fa2_stamp_buf));
+}
+#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -350,6 +362,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void fa2_fwd_mfma8x_kernel(const F8Ar
     };
     auto unit_masked = [&](int u) __attribute__((always_inline)) { return (CAUSAL && (u * 64 + 63 > q0)) || (u * 64 + 64 > N); };
 
+#ifdef FA2_STAMPS
+    unsigned long long st_acc[16] = {0}, st_last = 0;
+#endif
     for (int pass = 0; pass < npass; ++pass) {
         const int qi = pass == 0 ? qi_first : qi_second;
         q0 = qi * BR + wave * 32;
@@ -438,16 +453,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void fa2_fwd_mfma8x_kernel(const F8Ar
                 qk(n0, knext);
                 qk(n1, knext + 32 * ROWB);
                 finish(c0, c1, pf);
-    #if FA2_8X_ABL != 5   /* 5: no P.V */
+#if FA2_8X_ABL != 5   /* 5: no P.V */
                 pv(pf, vcur);
-    #else
+#else
                 asm volatile("" ::"v"(pf));
-    #endif
+#endif
                 fire = partial(n0, n1, t + 1, coeff, false);
+                STAMP(0);
                 dma_wait();
-    #if FA2_8X_ABL != 4   /* 4: no barrier in the steady loop */
+                STAMP(1);
+#if FA2_8X_ABL != 4   /* 4: no barrier in the steady loop */
                 __syncthreads();
-    #endif
+#endif
+                STAMP(2);
+#ifdef FA2_STAMPS
+                st_acc[15] += 1;
+#endif
             };
             auto guarded = [&](int t, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) __attribute__((always_inline)) {
                 if (t + 1 < nt) {
@@ -470,6 +491,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void fa2_fwd_mfma8x_kernel(const F8Ar
                 __syncthreads();
             };
             int t = 0;
+#ifdef FA2_STAMPS
+            st_last = __builtin_amdgcn_s_memtime();
+#endif
             for (; t + 1 < t_steady; t += 2) {
                 steady(t, sA, sB, sC, sD);
                 steady(t + 1, sC, sD, sA, sB);
@@ -515,6 +539,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void fa2_fwd_mfma8x_kernel(const F8Ar
         }
         if (pass + 1 < npass) __syncthreads();  // the next pass's DMA reuses the slices
     }  // pass
+#ifdef FA2_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) fa2_stamp_buf[wave][k] = st_acc[k];
+#endif
 }
 
 template <bool E4M3, int NW, int WPS = 2> int launch_t(const Fa2Problem &p, const F8Args &a) {
