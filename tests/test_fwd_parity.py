@@ -388,6 +388,40 @@ def test_no_out_of_bounds_writes_for_ragged_N():
         assert torch.isfinite(O.float()).all() and (O.float().abs() < 7).all()
 
 
+def test_hip_graph_capture_and_replay():
+    """The launch path has no allocation and no synchronisation (contract table): forward and backward
+    can be captured into a HIP graph after one warm-up call (the first call of a kernel family sets its LDS attribute)
+    and replayed on new contents of the same buffers, bit-identical to eager launches."""
+    from flash_attention_dlrs_amd import flash_attention_backward
+    for dtype, shape, causal in ((torch.bfloat16, (2, 4, 512, 128), True), (torch.float8_e4m3fn, (1, 4, 320, 128), False),
+                                 (torch.float32, (1, 2, 200, 64), False)):
+        gen = torch.Generator().manual_seed(5)
+        mk = lambda: (torch.randn(*shape, generator=gen) * 0.5).to(dtype).to(DEV)
+        Q, K, V, dO = mk(), mk(), mk(), mk()
+        bwd = dtype != torch.float8_e4m3fn  # the backward rejects fp8
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on the capture stream
+            O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal)
+            if bwd:
+                flash_attention_backward(Q, K, V, O, dO, L, DEV, causal=causal)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            O_g, L_g = fa.flash_attention_forward(Q, K, V, DEV, causal=causal)
+            grads_g = flash_attention_backward(Q, K, V, O_g, dO, L_g, DEV, causal=causal) if bwd else ()
+        for t in (Q, K, V, dO):
+            t.copy_(mk())
+        g.replay()
+        torch.cuda.synchronize()
+        O_e, L_e = fa.flash_attention_forward(Q, K, V, DEV, causal=causal)
+        raw = lambda t: t.view(torch.uint8) if t.element_size() == 1 else t
+        assert torch.equal(raw(O_g), raw(O_e)) and torch.equal(raw(L_g), raw(L_e))
+        if bwd:
+            grads_e = flash_attention_backward(Q, K, V, O_e, dO, L_e, DEV, causal=causal)
+            assert all(torch.equal(a, b) for a, b in zip(grads_g, grads_e))
+
+
 def test_unsupported_variant_and_dtype_errors():
     x = torch.zeros(1, 1, 32, 32, device=DEV)
     with pytest.raises(TypeError):
