@@ -64,6 +64,17 @@ int pick_variant(const Fa2Problem &p) {
                             (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
         if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
+        // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and
+        // every workgroup walks its key tiles in sequence -- latency-bound.  MFMA16K splits the keys of a tile among
+        // wave groups of the same workgroup (no workspace): benchmarks/tiny_grid.py, HIP-graph replay, fp16:
+        // B2 H8 N1024 d64 (BASELINE.json configs[1]) 16.8 -> 11.2 us; d = 128 25.3 -> 21.2; causal d = 128 38.6 -> 21.2;
+        // B1 H8 N4096 d128 causal 112.8 -> 79.3.  At 192 units and above the plain kernels are as fast or faster.
+        const long long wg128 = (long long)((p.N + 127) / 128) * p.B * p.H;
+        if ((p.causal ? wg128 / 2 : wg128) <= 128) {
+            if (wg128 > 128) return FA2_VARIANT_MFMA16K;  // causal, 129..256 tiles: 128-row tiles, two key groups
+            if (p.d == 64 && p.N >= 512) return FA2_VARIANT_MFMA16K_R2K4;
+            return FA2_VARIANT_MFMA16K_R2K2;
+        }
         if (wg256 < 512) return FA2_VARIANT_MFMA16D_W4;
         // 8-wave tiles: MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop).  Against MFMA16D on
         // MI355X (benchmarks/lottery.py, alternating order): non-causal +4.4 % (d = 128, N = 4096), +3.4 % (N = 8192),
@@ -98,6 +109,9 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA8X: return fa2_launch_mfma8x(p, 8);
     case FA2_VARIANT_MFMA8X_W4: return fa2_launch_mfma8x(p, 4);
     case FA2_VARIANT_MFMA8U: return fa2_launch_mfma8x(p, 12);
+    case FA2_VARIANT_MFMA16K: return fa2_launch_mfma16k(p, 42);
+    case FA2_VARIANT_MFMA16K_R2K2: return fa2_launch_mfma16k(p, 22);
+    case FA2_VARIANT_MFMA16K_R2K4: return fa2_launch_mfma16k(p, 24);
     case FA2_VARIANT_MFMA16D: return fa2_launch_mfma16d(p, 8);
     case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
     case FA2_VARIANT_MFMA16H: return fa2_launch_mfma16h(p, 8);
@@ -214,6 +228,9 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA8X: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8X_W4: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_MFMA8U: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA16K: out4[1] = 128; out4[2] = 64; out4[3] = 8; break;
+    case FA2_VARIANT_MFMA16K_R2K2: out4[1] = 64; out4[2] = 64; out4[3] = 4; break;
+    case FA2_VARIANT_MFMA16K_R2K4: out4[1] = 64; out4[2] = 64; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16D: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16H: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;

@@ -26,6 +26,7 @@ int fa2_launch_mfma16x(const Fa2Problem &p, int abl);
 int fa2_launch_mfma16d(const Fa2Problem &p, int waves);
 int fa2_launch_mfma8(const Fa2Problem &p, int waves);
 int fa2_launch_mfma8x(const Fa2Problem &p, int waves);
+int fa2_launch_mfma16k(const Fa2Problem &p, int shape);
 int fa2_launch_mfma16s(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16h(const Fa2Problem &p, int waves);  // dispatches to the two translation units below
 int fa2_launch_mfma16h_causal(const Fa2Problem &p, int waves);

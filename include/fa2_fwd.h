@@ -65,6 +65,9 @@ extern "C" {
 #define FA2_VARIANT_MFMA8X 16 /* fp8 on the double-rate v_mfma_f32_32x32x64_f8f6f4: 64-key units, 8 waves x 32 rows       */
 #define FA2_VARIANT_MFMA8X_W4 17 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA8U 18 /* MFMA8X_W4 unpipelined at <= 168 registers: three workgroups (12 waves) per CU            */
+#define FA2_VARIANT_MFMA16K 19 /* f16/bf16 small grids: 8 waves on a 128-row tile, waves w and w+4 split the KEYS and merge through LDS */
+#define FA2_VARIANT_MFMA16K_R2K2 20 /* same with a 64-row tile: 2 row blocks x 2 key groups, four waves                    */
+#define FA2_VARIANT_MFMA16K_R2K4 23 /* 64-row tile, 2 row blocks x 4 key groups, eight waves (d = 64)                       */
 #define FA2_VARIANT_MFMA16X 7 /* f16/bf16, d = 128: 4 waves x 64 rows, one wave per SIMD, every K/V    */
                               /* fragment read from LDS feeds two MFMAs                              */
 

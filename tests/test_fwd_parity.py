@@ -43,9 +43,11 @@ def hip_forward(Q, K, V, causal=False, scale=1.0, variant="auto"):
 def supported_variants(dtype, d):
     v = ["auto", "generic"]
     if dtype in (torch.float16, torch.bfloat16) and d in (64, 128):
-        v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2", "mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4"]
+        v += ["mfma16", "mfma16_w8", "mfma16p", "mfma16p_w8", "mfma16p_w8_x1", "mfma16p_w8_x2", "mfma16p_x2", "mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16k", "mfma16k_r2k2"]
         if d == 128:
             v += ["mfma16x", "mfma16s", "mfma16s_w4"]
+        else:
+            v += ["mfma16k_r2k4"]
     if dtype == torch.float32 and d in (64, 128):
         v += ["mfma32"]
     return v
@@ -375,6 +377,7 @@ def test_no_out_of_bounds_writes_for_ragged_N():
                               (torch.bfloat16, "mfma16_w8", 64), (torch.float32, "generic", 64),
                               (torch.bfloat16, "mfma16d", 128), (torch.bfloat16, "mfma16s", 128),
                               (torch.bfloat16, "mfma16h", 128), (torch.float16, "mfma16h_w4", 64),
+                              (torch.bfloat16, "mfma16k", 128), (torch.float16, "mfma16k", 64),
                               (torch.float8_e4m3fn, "mfma8x", 128), (torch.float8_e5m2, "mfma8x_w4", 128),
                               (torch.float8_e4m3fn, "mfma8", 128)):
         B, H, N = 1, 2, 77
