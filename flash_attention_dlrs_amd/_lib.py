@@ -64,6 +64,10 @@ def lib():
         l.fa2_fwd.argtypes = common
         l.fa2_fwd_variant.restype = ctypes.c_int
         l.fa2_fwd_variant.argtypes = common + [ctypes.c_int32]
+        # second prototype of the same entry for the hot path: the five stride pointers as plain addresses into ONE
+        # int64 array (fa2_fwd below), which saves building five ctypes arrays per launch
+        l.fwd_variant_addr = ctypes.CFUNCTYPE(ctypes.c_int, *([vp] * 10 + [ctypes.c_int32] * 6 + [ctypes.c_float, vp, ctypes.c_int32]))(
+            ("fa2_fwd_variant", l))
         l.fa2_query_tile.restype = ctypes.c_int
         l.fa2_query_tile.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
         bwd = [vp] * 10 + [i64p] * 9 + [ctypes.c_int32] * 6 + [ctypes.c_float, vp]
@@ -71,6 +75,8 @@ def lib():
         l.fa2_bwd.argtypes = bwd
         l.fa2_bwd_variant.restype = ctypes.c_int
         l.fa2_bwd_variant.argtypes = bwd + [ctypes.c_int32]
+        l.bwd_variant_addr = ctypes.CFUNCTYPE(ctypes.c_int, *([vp] * 19 + [ctypes.c_int32] * 6 + [ctypes.c_float, vp, ctypes.c_int32]))(
+            ("fa2_bwd_variant", l))
         l.fa2_version.restype = ctypes.c_char_p
         l.fa2_last_error.restype = ctypes.c_char_p
         _lib = l
@@ -102,6 +108,14 @@ def _i64(vals):
     return (ctypes.c_int64 * len(vals))(*vals)
 
 
+def _raw_stream(index):
+    """Handle of torch's current stream on device `index`."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(index)
+    except AttributeError:  # older / newer torch without the private accessor
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 def fa2_fwd(Q, K, V, O, L, dtype_enum, causal=False, scale=1.0, variant=VARIANT_AUTO):
     """Launch the forward on the current stream of Q's device.  Tensors are (B, H, N, d) with
     arbitrary strides; O (B, H, N, d) and L (B, H, N, 1) are pre-allocated by the caller exactly as
@@ -110,12 +124,22 @@ def fa2_fwd(Q, K, V, O, L, dtype_enum, causal=False, scale=1.0, variant=VARIANT_
         raise NotImplementedError("Q, K, V must be on the same CUDA device")
     B, H, N, d = Q.shape
     LB, LH = L.stride(0), L.stride(1)
-    with torch.cuda.device(Q.device):
-        stream = torch.cuda.current_stream(Q.device).cuda_stream
-        rc = lib().fa2_fwd_variant(
+
+    def launch():
+        # one int64 array for the 18 strides (five ctypes arrays cost ~2 us), raw stream handle without the Stream object
+        st = (ctypes.c_int64 * 18)(*Q.stride(), *K.stride(), *V.stride(), *O.stride(), LB, LH)
+        base = ctypes.addressof(st)
+        return lib().fwd_variant_addr(
             Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), L.data_ptr(),
-            _i64(Q.stride()), _i64(K.stride()), _i64(V.stride()), _i64(O.stride()), _i64((LB, LH)),
-            B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), stream, int(variant))
+            base, base + 32, base + 64, base + 96, base + 128,
+            B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), _raw_stream(Q.device.index), int(variant))
+    # the library launches on the CURRENT HIP device: switch only if it is not the tensors' one (the device guard
+    # costs several microseconds of the ~15 a small launch takes on the host)
+    if torch.cuda.current_device() == Q.device.index:
+        rc = launch()
+    else:
+        with torch.cuda.device(Q.device):
+            rc = launch()
     if rc != 0:
         _raise(rc)
 
@@ -128,13 +152,20 @@ def fa2_bwd(Q, K, V, O, dO, L, dQ, dK, dV, D, dtype_enum, causal=False, scale=1.
         raise NotImplementedError("Q, K, V must be on the same CUDA device")
     B, H, N, d = Q.shape
     assert D.is_contiguous() and D.numel() == 2 * B * H * N
-    with torch.cuda.device(Q.device):
-        stream = torch.cuda.current_stream(Q.device).cuda_stream
-        rc = lib().fa2_bwd_variant(
+
+    def launch():
+        st = (ctypes.c_int64 * 34)(*Q.stride(), *K.stride(), *V.stride(), *O.stride(), *dO.stride(), *dQ.stride(),
+                                    *dK.stride(), *dV.stride(), L.stride(0), L.stride(1))
+        base = ctypes.addressof(st)
+        return lib().bwd_variant_addr(
             Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), dO.data_ptr(), L.data_ptr(),
             dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), D.data_ptr(),
-            _i64(Q.stride()), _i64(K.stride()), _i64(V.stride()), _i64(O.stride()), _i64(dO.stride()),
-            _i64(dQ.stride()), _i64(dK.stride()), _i64(dV.stride()), _i64((L.stride(0), L.stride(1))),
-            B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), stream, int(variant))
+            *(base + 32 * k for k in range(9)),
+            B, H, N, d, int(dtype_enum), int(bool(causal)), float(scale), _raw_stream(Q.device.index), int(variant))
+    if torch.cuda.current_device() == Q.device.index:
+        rc = launch()
+    else:
+        with torch.cuda.device(Q.device):
+            rc = launch()
     if rc != 0:
         _raise(rc)

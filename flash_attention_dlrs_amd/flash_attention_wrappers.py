@@ -31,11 +31,11 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
 
     dtype = convert_triton_dtype(Q.dtype)
     v = _lib.VARIANTS[variant]
-    if variant == "auto":
-        v = autotune.pick(Q, K, V, O, L, dtype, causal, scale)  # VARIANT_AUTO unless FA2_AUTOTUNE=1
+    if variant == "auto" and autotune.enabled():
+        v = autotune.pick(Q, K, V, O, L, dtype, causal, scale)  # the on-box tuner, FA2_AUTOTUNE=1
     _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
 
-    return O[:, :, :, 0:d], L
+    return (O if d_pow == d else O[:, :, :, 0:d]), L
 
 
 def flash_attention_backward(Q, K, V, O, dO, L, dev, deterministic=False, *, causal=False, scale=1.0, variant="auto"):
