@@ -75,7 +75,25 @@ int pick_variant(const Fa2Problem &p) {
             if (p.d == 64 && p.N >= 512) return FA2_VARIANT_MFMA16K_R2K4;
             return FA2_VARIANT_MFMA16K_R2K2;
         }
-        if (wg256 < 512) return FA2_VARIANT_MFMA16D_W4;
+        // Mid-size grids (benchmarks/mid_grid.py, profiles/r01/mid_grid_bf16.jsonl: 96 shapes, bf16, 64..1024 256-row
+        // tiles).  MFMA16H is a persistent grid of one 8-wave workgroup per CU: its time goes in steps of whole jobs per
+        // CU (256-row tiles, tile PAIRS when causal), so it wants the job count near a multiple of 256; the 4-wave
+        // MFMA16D_W4 has twice the jobs at half the size.  Readings behind the rules: d = 128 non-causal, 192 / 256 tiles:
+        // MFMA16H -12..16 % / -5..10 %, 384 tiles (1.5 jobs per CU): MFMA16D_W4 -5 %; d = 128 causal, 384 tiles: MFMA16H
+        // -16..19 %; d = 64 causal, 768 tiles (1.5 pairs per CU): MFMA16D_W4
+        // -20 %, 256 tiles: MFMA16D_W4 -25 %.
+        const int nq256 = (p.N + 255) / 256;
+        const long long jobs = (long long)(p.causal ? (nq256 + 1) / 2 : nq256) * p.B * p.H;  // of MFMA16H
+        const double x = (double)jobs / 256.0;
+        const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + 255) / 256) / x <= 1.2;  // <= 20 % lost to whole jobs
+        // (two full rounds of the 8-wave key-split workgroups: B1 H16 N4096 98 vs 105 us, B1 H8 N8192 173 vs 191; at
+        // 1.5 rounds -- 384 tiles -- it loses 50 %)
+        if (p.causal && p.d == 128 && wg128 > 448 && wg128 <= 512 && p.N >= 4096) return FA2_VARIANT_MFMA16K;
+        if (p.d == 128) {
+            if (p.causal ? wg256 < 320 : (wg256 < 160 || !even)) return FA2_VARIANT_MFMA16D_W4;
+        } else {
+            if (wg256 < 160 || !even) return FA2_VARIANT_MFMA16D_W4;
+        }
         // 8-wave tiles: MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop).  Against MFMA16D on
         // MI355X (benchmarks/lottery.py, alternating order): non-causal +4.4 % (d = 128, N = 4096), +3.4 % (N = 8192),
         // +9 % (d = 64); causal, once its causal kernels got a translation unit of their own: +4.1 % at the north-star
