@@ -103,8 +103,15 @@ int pick_variant(const Fa2Problem &p) {
     if (fa2_mfma8x_supports(p)) {
         // fp8: the double-rate k = 64 MFMA (64-key units).  Against MFMA8 (32x32x16 fp8, the bf16 rate) on MI355X:
         // +26 % at the c5 per-GPU shape (N = 16384 non-causal: 1 880 vs 1 492 TFLOP/s), +19 % at c3 causal.
-        const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
-        return wg256 >= 512 ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
+        // 8 waves (one workgroup per CU) when the job count -- 256-row tiles, tile pairs when causal -- fills the 256 CUs
+        // evenly, else 4 waves: the rule of the bf16 table above, checked on 52 fp8 shapes (benchmarks/mid_grid_fp8.py,
+        // profiles/r01/mid_grid_fp8.jsonl; the old single threshold lost up to 20 % at 1.5 jobs per CU).
+        const int nq256 = (p.N + 255) / 256;
+        const long long wg256 = (long long)nq256 * p.B * p.H;
+        const long long jobs = (long long)(p.causal ? (nq256 + 1) / 2 : nq256) * p.B * p.H;
+        const double x = (double)jobs / 256.0;
+        const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + 255) / 256) / x <= 1.2;
+        return wg256 >= 160 && even ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
     }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;
     return FA2_VARIANT_GENERIC;
