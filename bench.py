@@ -114,6 +114,21 @@ def profiled_traffic(config, variant):
     return best
 
 
+def measured_peak(dtype):
+    """MFMA-only rate of this dtype's matrix instruction measured on an MI355X with non-zero operands
+    (scripts/probes/mfma_peak.hip -> profiles/rNN/roofline.json) -- context for `frac`, which stays against the vendor
+    peak.  None if no probe result is committed."""
+    import glob
+    key = {"bf16": "bf16_random", "fp16": "bf16_random", "fp8": "fp8_random", "f32": "f32_random"}.get(dtype)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "roofline.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                return {"tflops": json.load(fh)["mfma_only_tflops"][key], "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,7 +279,8 @@ def main():
                          "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes": (4 * c["d"] + 1) * c["B"] * c["H"] * c["N"] * Q.element_size(),
                          "kernel_ms_avg": round(kern_avg, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
-                         "kernel_ms_min": round(kern_ms[0], 5)},
+                         "kernel_ms_min": round(kern_ms[0], 5),
+                         "measured_mfma_only_peak": measured_peak(c["dtype"])},
             "cpu_baseline": cpu,
             "extras": extras,
             "lib": _lib.version(),
