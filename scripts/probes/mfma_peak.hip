@@ -37,6 +37,33 @@ template <int MODE> __global__ __launch_bounds__(512, 2) void peak(float *out, i
         for (int it = 0; it < iters; ++it)
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[k], 0, 0, 0, 0, 0, 0);
+    } else if (MODE == 3) {  // bf16 on the other matrix shape, 16x16x32 (four accumulators of 4 registers)
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = (__bf16)(seed ? ((int)(next() >> 24) - 128) / 64.0f : 0.0f);
+            b[j] = (__bf16)(seed ? ((int)(next() >> 24) - 128) / 64.0f : 0.0f);
+        }
+        f32x4 c4[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c4[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c4[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c4[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k & 3][k >> 2] += c4[k][0] + c4[k][3];
+    } else if (MODE == 4) {  // f16 32x32x16
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+        f16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = (_Float16)(seed ? ((int)(next() >> 24) - 128) / 64.0f : 0.0f);
+            b[j] = (_Float16)(seed ? ((int)(next() >> 24) - 128) / 64.0f : 0.0f);
+        }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
     } else {
         float a = seed ? ((int)(next() >> 24) - 128) / 64.0f : 0.0f, b = seed ? ((int)(next() >> 24) - 128) / 64.0f : 0.0f;
         for (int it = 0; it < iters; ++it)
@@ -51,7 +78,7 @@ template <int MODE> __global__ __launch_bounds__(512, 2) void peak(float *out, i
     if (s == 12345.678f) out[0] = s;
 }
 
-template <int MODE> double run(int cus, unsigned seed, double flop_per_mfma) {
+template <int MODE> double run(int cus, unsigned seed, double flop_per_mfma, int per_iter = 4) {
     float *out;
     (void)hipMalloc(&out, 4);
     const int iters = 20000, wgs = cus;  // one 8-wave workgroup per CU = 2 waves per SIMD
@@ -69,7 +96,7 @@ template <int MODE> double run(int cus, unsigned seed, double flop_per_mfma) {
         if (rep >= 1 && ms < best) best = ms;  // rep 0 = clock ramp
     }
     (void)hipFree(out);
-    return (double)wgs * 8 * iters * 4 * flop_per_mfma / (best * 1e-3) * 1e-12;
+    return (double)wgs * 8 * iters * per_iter * flop_per_mfma / (best * 1e-3) * 1e-12;
 }
 
 int main() {
@@ -80,8 +107,10 @@ int main() {
     printf("{\"device\": \"%s\", \"arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"lds_per_cu_kib\": %d, "
            "\"vendor_peak_tflops\": {\"bf16\": 2500, \"fp8\": 5000, \"f32_matrix\": 157.3}, "
            "\"mfma_only_tflops\": {\"bf16_zeros\": %.0f, \"bf16_random\": %.0f, \"fp8_zeros\": %.0f, \"fp8_random\": %.0f, "
-           "\"f32_zeros\": %.1f, \"f32_random\": %.1f}}\n",
+           "\"f32_zeros\": %.1f, \"f32_random\": %.1f, \"bf16_16x16x32_zeros\": %.0f, \"bf16_16x16x32_random\": %.0f, "
+           "\"f16_zeros\": %.0f, \"f16_random\": %.0f}}\n",
            p.name, p.gcnArchName, cus, p.clockRate / 1000, (int)(p.maxSharedMemoryPerMultiProcessor / 1024),
-           run<0>(cus, 0, bf), run<0>(cus, 7, bf), run<1>(cus, 0, f8), run<1>(cus, 7, f8), run<2>(cus, 0, f32), run<2>(cus, 7, f32));
+           run<0>(cus, 0, bf), run<0>(cus, 7, bf), run<1>(cus, 0, f8), run<1>(cus, 7, f8), run<2>(cus, 0, f32), run<2>(cus, 7, f32),
+           run<3>(cus, 0, 2.0 * 16 * 16 * 32, 8), run<3>(cus, 7, 2.0 * 16 * 16 * 32, 8), run<4>(cus, 0, bf), run<4>(cus, 7, bf));
     return 0;
 }
