@@ -1,0 +1,116 @@
+"""Static wait-state checker for a generated instruction list (hipcc pads nothing in hand-written assembly).
+
+Rules (ROCm 7.2 hazard recognizer as observed for gfx950, cdna_hip_programming.md section 5.7; distances are wait states:
+every instruction in between counts one, `s_nop N` counts N + 1):
+  R1  MFMA (8-pass) result -> read or overwritten by anything but the next MFMA of its own accumulate chain: >= 12
+  R2  VALU result -> MFMA operand: >= 2
+  R3  transcendental result -> other VALU: >= 1
+  R4  VALU result -> v_permlane32_swap operand: >= 2
+  R5  VALU result -> v_readfirstlane source: >= 1
+  R6  VALU-written SGPR (v_readfirstlane, v_cmp) -> VMEM / SMEM / SALU reader: >= 5 (only VMEM needs it; kept strict)
+  R7  SALU write of M0 -> LDS-DMA: >= 1
+  R8  MFMA C operand -> overwritten by VALU: >= 12
+The scan is linear over the listing (labels do not reset it): blocks reached by a taken branch must open with their own pad.
+"""
+from __future__ import annotations
+
+from .isa import Inst, TRANS_OPS
+
+
+def wait_states(ins: Inst) -> int:
+    if ins.op in (".label", ".comment"):
+        return 0
+    if ins.op == "s_nop":
+        return ins.ops[0] + 1
+    return 1
+
+
+def check(prog, verbose=True):
+    last_mfma_def = {}    # reg -> (pos, inst index, dst-range tuple)
+    last_mfma_csrc = {}   # reg -> pos (read as C by an MFMA)
+    last_valu_def = {}    # reg -> pos
+    last_trans_def = {}
+    last_valu_sgpr = {}
+    last_m0 = -100
+    pos = 0
+    errs = []
+    for idx, ins in enumerate(prog):
+        ws = wait_states(ins)
+        if ws == 0:
+            continue
+        d, u = ins.defs_uses()
+        here = pos
+
+        def dist(p):
+            return here - p - 1  # wait states strictly between
+
+        if ins.is_mfma:
+            dst = tuple(ins.ops[0].regs())
+            csrc = tuple(ins.ops[3].regs()) if hasattr(ins.ops[3], "regs") else ()
+            for r in u:
+                if r in last_mfma_def:
+                    p, _, rng = last_mfma_def[r]
+                    same_chain = (r in csrc) and rng == dst and csrc == dst
+                    if not same_chain and dist(p) < 12:
+                        errs.append((idx, "R1 mfma->mfma operand", r, dist(p)))
+                if r in last_valu_def and dist(last_valu_def[r]) < 2:
+                    errs.append((idx, "R2 valu->mfma", r, dist(last_valu_def[r])))
+            for r in d:
+                if r in last_mfma_def:
+                    p, _, rng = last_mfma_def[r]
+                    if not (rng == dst and csrc == dst) and dist(p) < 12:
+                        errs.append((idx, "R1 mfma->mfma overwrite", r, dist(p)))
+            for r in csrc:
+                last_mfma_csrc[r] = here
+            for r in dst:
+                last_mfma_def[r] = (here, idx, dst)
+                last_valu_def.pop(r, None)
+                last_trans_def.pop(r, None)
+        else:
+            for r in list(u) + list(d):
+                if r in last_mfma_def and dist(last_mfma_def[r][0]) < 12:
+                    errs.append((idx, "R1 mfma result touched", r, dist(last_mfma_def[r][0])))
+            if ins.is_valu:
+                for r in d:
+                    if r in last_mfma_csrc and dist(last_mfma_csrc[r]) < 12:
+                        errs.append((idx, "R8 mfma C overwritten", r, dist(last_mfma_csrc[r])))
+                if ins.op not in TRANS_OPS:
+                    for r in u:
+                        if r in last_trans_def and dist(last_trans_def[r]) < 1:
+                            errs.append((idx, "R3 trans->valu", r, dist(last_trans_def[r])))
+                if ins.op == "v_permlane32_swap_b32":
+                    for r in u:
+                        if r in last_valu_def and dist(last_valu_def[r]) < 2:
+                            errs.append((idx, "R4 valu->permlane", r, dist(last_valu_def[r])))
+                if ins.op == "v_readfirstlane_b32":
+                    for r in u:
+                        if r in last_valu_def and dist(last_valu_def[r]) < 1:
+                            errs.append((idx, "R5 valu->readfirstlane", r, dist(last_valu_def[r])))
+            elif not ins.op.startswith("s_cbranch_vcc"):  # v_cmp -> s_cbranch_vcc* needs nothing (hipcc emits them adjacent)
+                for r in u:
+                    if r[0] == "s" and r in last_valu_sgpr and dist(last_valu_sgpr[r]) < 5:
+                        errs.append((idx, "R6 valu sgpr->reader", r, dist(last_valu_sgpr[r])))
+            if ins.op.startswith("buffer_load") and ins.mods.get("lds") and dist(last_m0) < 1:
+                errs.append((idx, "R7 m0->lds dma", ("s", 124), dist(last_m0)))
+            for r in d:
+                last_mfma_def.pop(r, None)
+                if ins.is_valu:
+                    if r[0] == "s":
+                        last_valu_sgpr[r] = here
+                    else:
+                        last_valu_def[r] = here
+                        if ins.op in TRANS_OPS:
+                            last_trans_def[r] = here
+                        else:
+                            last_trans_def.pop(r, None)
+                else:
+                    last_valu_def.pop(r, None)
+                    last_trans_def.pop(r, None)
+                    last_valu_sgpr.pop(r, None)
+                    if r == ("s", 124):
+                        last_m0 = here
+        pos += ws
+    if verbose:
+        for idx, rule, r, dd in errs[:40]:
+            print(f"  hazard {rule}: inst {idx} `{prog[idx].text().strip()}` reg {r} distance {dd}")
+    return errs

@@ -1,0 +1,142 @@
+// fa2_a64.hip -- host side of the generated assembly kernels `fa2_fwd_a64_<dtype>_<c|n>` (variant "a64"):
+// f16 / bf16, d = 128, N a multiple of 256; 4 waves x 64 query rows, one wave per SIMD with the whole register file,
+// persistent grid.  The kernels are produced by asm/fa2_a64_gen.py (instruction stream, register map and kernel-argument
+// layout are documented there), assembled into a gfx950 code object and embedded in this library (fa2_a64_blob.S); they
+// are loaded once per device with hipModuleLoadData and launched with hipModuleLaunchKernel.
+// Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "fa2_common.h"
+
+extern "C" const unsigned char fa2_a64_hsaco_start[];
+extern "C" const unsigned char fa2_a64_hsaco_end[];
+
+namespace {
+
+// kernel-argument block: the layout of Gen.k_setup() in asm/fa2_a64_gen.py (184 bytes)
+struct __attribute__((packed)) A64Args {
+    const void *Q, *K, *V;
+    void *O, *L;
+    int64_t qs_b, qs_h, ks_b, ks_h, vs_b, vs_h, os_b, os_h, ls_b, ls_h;  // bytes
+    int32_t qs_n, ks_n, vs_n, os_n;                                        // bytes
+    int32_t N, H, nq, total;
+    float c_log2e, thr;
+    int32_t nunit, group;
+    int32_t nbh, nwg;
+    void *dbg;
+};
+static_assert(sizeof(A64Args) == 184, "kernel-argument layout");
+
+constexpr int kMaxDev = 64;
+struct DevState {
+    bool ready = false, failed = false;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [bf16 / f16][non-causal / causal]
+    int cus = 0;
+};
+DevState g_dev[kMaxDev];
+std::mutex g_mu;
+
+DevState *dev_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+        fa2_set_error("a64: hipGetDevice failed or device ordinal out of range");
+        return nullptr;
+    }
+    DevState &d = g_dev[dev];
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (d.ready) return &d;
+    if (d.failed) {
+        fa2_set_error("a64: code object could not be loaded on device %d", dev);
+        return nullptr;
+    }
+    hipError_t e = hipModuleLoadData(&d.mod, (const void *)fa2_a64_hsaco_start);
+    if (e != hipSuccess) {
+        d.failed = true;
+        fa2_set_error("a64: hipModuleLoadData failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    static const char *names[2][2] = {{"fa2_fwd_a64_bf16_n", "fa2_fwd_a64_bf16_c"}, {"fa2_fwd_a64_f16_n", "fa2_fwd_a64_f16_c"}};
+    for (int t = 0; t < 2; ++t)
+        for (int c = 0; c < 2; ++c) {
+            e = hipModuleGetFunction(&d.fn[t][c], d.mod, names[t][c]);
+            if (e != hipSuccess) d.fn[t][c] = nullptr;  // a kernel the generator did not emit: reported at launch
+        }
+    (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    d.cus = n;
+    d.ready = true;
+    return &d;
+}
+
+}  // namespace
+
+bool fa2_a64_supports(const Fa2Problem &p) {
+    if (p.dtype != FA2_DTYPE_BF16 && p.dtype != FA2_DTYPE_F16) return false;
+    if (p.d != 128 || p.N < 256 || (p.N & 255)) return false;
+    if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
+    if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
+    const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
+    for (int k = 0; k < 4; ++k)
+        if (rows[k] < 128 || (rows[k] & 7) || (int64_t)(p.N + 512) * rows[k] * 2 >= (1LL << 31)) return false;
+    const uintptr_t ptrs[4] = {(uintptr_t)p.Q, (uintptr_t)p.K, (uintptr_t)p.V, (uintptr_t)p.O};
+    for (int k = 0; k < 4; ++k)
+        if (ptrs[k] & 15) return false;
+    if (((p.qs[0] | p.qs[1] | p.ks[0] | p.ks[1] | p.vs[0] | p.vs[1] | p.os[0] | p.os[1]) & 7) != 0) return false;
+    if ((uintptr_t)p.L & 1) return false;
+    const int64_t nq = p.N / 256, jobs = (int64_t)p.B * p.H * nq;
+    if (jobs >= (1 << 22) || p.H >= (1 << 22) || p.ls[1] < p.N) return false;
+    return true;
+}
+
+int fa2_launch_a64(const Fa2Problem &p) {
+    if (!fa2_a64_supports(p)) {
+        fa2_set_error("a64 kernel: needs f16/bf16, d = 128, N a multiple of 256, unit d-stride, 16-byte aligned rows, "
+                      "scale > 0, N * row stride < 2 GiB");
+        return FA2_ERR_UNSUPPORTED;
+    }
+    DevState *d = dev_state();
+    if (!d) return FA2_ERR_LAUNCH;
+    hipFunction_t fn = d->fn[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0];
+    if (!fn) {
+        fa2_set_error("a64 kernel: this (dtype, causal) form is not in the code object");
+        return FA2_ERR_UNSUPPORTED;
+    }
+    A64Args a;
+    memset(&a, 0, sizeof(a));
+    a.Q = p.Q; a.K = p.K; a.V = p.V; a.O = p.O; a.L = p.L;
+    a.qs_b = p.qs[0] * 2; a.qs_h = p.qs[1] * 2; a.ks_b = p.ks[0] * 2; a.ks_h = p.ks[1] * 2;
+    a.vs_b = p.vs[0] * 2; a.vs_h = p.vs[1] * 2; a.os_b = p.os[0] * 2; a.os_h = p.os[1] * 2;
+    a.ls_b = p.ls[0] * 2; a.ls_h = p.ls[1] * 2;
+    a.qs_n = (int32_t)(p.qs[2] * 2); a.ks_n = (int32_t)(p.ks[2] * 2); a.vs_n = (int32_t)(p.vs[2] * 2); a.os_n = (int32_t)(p.os[2] * 2);
+    a.N = p.N; a.H = p.H; a.nq = p.N / 256;
+    a.nunit = p.causal ? (a.nq + 1) / 2 : a.nq;
+    a.nbh = p.B * p.H;
+    a.total = a.nunit * a.nbh;
+    a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
+    a.thr = p.dtype == FA2_DTYPE_F16 ? 12.0f : 24.0f;  // deferred running-max threshold, see fa2_mfma16h.hip
+    a.group = 1;
+    if (p.causal && (a.nbh & 7) == 0) {
+        const int per_xcd = a.nbh / 8;
+        int g = 2 > per_xcd ? per_xcd : 2;
+        while (per_xcd % g) --g;
+        a.group = g;
+    }
+    // persistent grid: one workgroup per CU, a multiple of 8 when there is more work than CUs (XCD affinity of the units)
+    int slots = d->cus - d->cus % 8;
+    if (slots < 8) slots = 8;
+    a.nwg = a.total < slots ? a.total : slots;
+    a.dbg = nullptr;
+    size_t size = sizeof(a);
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)a.nwg, 1, 1, 256, 1, 1, 0, p.stream, nullptr, extra);
+    if (e != hipSuccess) {
+        fa2_set_error("a64 kernel launch failed: %s", hipGetErrorString(e));
+        return FA2_ERR_LAUNCH;
+    }
+    return FA2_OK;
+}

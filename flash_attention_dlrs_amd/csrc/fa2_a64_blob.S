@@ -1,0 +1,10 @@
+/* the gfx950 code object of asm/fa2_a64_gen.py, embedded as read-only data (see fa2_a64.hip) */
+    .section .rodata
+    .global fa2_a64_hsaco_start
+    .global fa2_a64_hsaco_end
+    .balign 4096
+fa2_a64_hsaco_start:
+    .incbin "fa2_a64.hsaco"
+fa2_a64_hsaco_end:
+    .byte 0
+    .section .note.GNU-stack,"",@progbits

@@ -141,6 +141,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16D_W4: return fa2_launch_mfma16d(p, 4);
     case FA2_VARIANT_MFMA16H: return fa2_launch_mfma16h(p, 8);
     case FA2_VARIANT_MFMA16H_W4: return fa2_launch_mfma16h(p, 4);
+    case FA2_VARIANT_A64: return fa2_launch_a64(p);
     case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
     case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
     case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
@@ -248,6 +249,7 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA16P: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16P_W8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16X: out4[1] = 256; out4[2] = 32; out4[3] = 4; break;
+    case FA2_VARIANT_A64: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_MFMA8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA8X: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;

@@ -68,6 +68,8 @@ extern "C" {
 #define FA2_VARIANT_MFMA16K 19 /* f16/bf16 small grids: 8 waves on a 128-row tile, waves w and w+4 split the KEYS and merge through LDS */
 #define FA2_VARIANT_MFMA16K_R2K2 20 /* same with a 64-row tile: 2 row blocks x 2 key groups, four waves                    */
 #define FA2_VARIANT_MFMA16K_R2K4 23 /* 64-row tile, 2 row blocks x 4 key groups, eight waves (d = 64)                       */
+#define FA2_VARIANT_A64 24 /* f16/bf16, d = 128, N % 256 == 0: generated gfx950 assembly, 4 waves x 64 rows, one wave per SIMD   */
+                           /* with the whole register file (O, Q, K in AGPRs), persistent grid                              */
 #define FA2_VARIANT_MFMA16X 7 /* f16/bf16, d = 128: 4 waves x 64 rows, one wave per SIMD, every K/V    */
                               /* fragment read from LDS feeds two MFMAs                              */
 
