@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Job timeline of the generated assembly kernel from in-kernel stamps (diagnostic library `make -C ... stamps`).
+
+    FA2_HIP_LIB=flash_attention_dlrs_amd/libfa2_hip_stamps.so python benchmarks/a64_stamps.py c3_noncausal
+
+Slots per (workgroup, wave): 0 job start (loop entry), 3 steady loop end, 4 seam body end, 5 epilogue end (all of the LAST
+job of the workgroup); 6 / 7 s_memrealtime (100 MHz) at kernel start / end, 8 / 9 s_memtime there; 10..12 cycles summed
+over the last job's steady loop: phase A, barrier wait, phase B.  The stamped build's run time is not the product's: read shares, not lengths.
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import CONFIGS, TORCH_DTYPE, flops  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3_noncausal"
+c = CONFIGS[cfg]
+dev = torch.device("cuda:0")
+NSLOT = 16
+nwg = 256
+dbg = torch.zeros(nwg * 4 * NSLOT, dtype=torch.int64, device=dev)
+os.environ["FA2_A64_DBG"] = hex(dbg.data_ptr())
+from flash_attention_dlrs_amd import flash_attention_forward  # noqa: E402
+
+torch.manual_seed(42)
+Q, K, V = (torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
+data = sys.argv[2] if len(sys.argv) > 2 else "randn"
+if data == "zeros":
+    Q.zero_(); K.zero_(); V.zero_()
+elif data == "kzero":      # scores all zero, V random
+    K.zero_()
+elif data == "vzero":
+    V.zero_()
+elif data == "small":      # the usual 1/sqrt(d) softmax scale folded into Q
+    Q.mul_(128 ** -0.5)
+elif data == "ones":
+    Q.fill_(0.1); K.fill_(0.1); V.fill_(1.0)
+for _ in range(20):
+    flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant="a64")
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(10):
+    flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant="a64")
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 10
+d = dbg.cpu().view(nwg, 4, NSLOT).double()
+tiles = c["N"] // 64
+out = {"config": cfg, "data": data, "kernel": os.environ.get("FA2_A64_KERNEL", ""), "ms": round(ms, 4), "tflops": round(flops(c) / ms / 1e9, 1)}
+seg = {"loop": d[..., 3] - d[..., 0], "seam": d[..., 4] - d[..., 3], "epilogue": d[..., 5] - d[..., 4], "kernel": d[..., 9] - d[..., 8]}
+for k, v in seg.items():
+    out[k + "_cyc_median"] = float(v.median())
+if not c["causal"]:
+    out["cyc_per_step_loop"] = round(float((seg["loop"] / (tiles - 4)).median()), 1)
+    out["cyc_per_mfma_loop"] = round(out["cyc_per_step_loop"] / 64, 2)
+lo = dbg.cpu().view(nwg, 4, NSLOT) & 0xFFFFFFFF
+steps = tiles - 4
+for k, nm in ((10, "phaseA"), (11, "sync"), (12, "phaseB")):
+    out[nm + "_cyc_per_step"] = [round(float(lo[:, w, k].double().median()) / steps, 1) for w in range(4)]
+real = (d[..., 7] - d[..., 6]).median().item()  # 100 MHz ticks
+out["clock_ghz"] = round(float(seg["kernel"].median()) / real / 10.0, 3) if real > 0 else None
+out["job_cyc"] = float((d[..., 5] - d[..., 0]).median())
+print(json.dumps(out))

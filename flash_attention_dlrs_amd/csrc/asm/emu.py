@@ -386,6 +386,28 @@ class Workgroup:
             w.s[dst.idx + k] = 0xDEADBEEF
         w.lgkm_q.append(apply)
 
+    def x_s_memtime(self, w, i):
+        dst, val = i.ops[0], w.n_exec * 4
+
+        def apply():
+            w.wr_s(dst, val)
+        apply.smem = True
+        w.lgkm_q.append(apply)
+
+    def x_s_memrealtime(self, w, i):
+        self.x_s_memtime(w, i)
+
+    def x_global_store_dwordx2(self, w, i):
+        vaddr, src, sbase = i.ops
+        base = w.rd_s(sbase)
+        off = w.rd_v(vaddr).astype(np.int64) + int(i.mods.get("offset", 0))
+        m = w.exec_mask()
+        d0, d1 = w.rd_v(src, 0), w.rd_v(src, 1)
+        for l in range(64):
+            if m[l]:
+                self.mem.write(base + int(off[l]), np.array([d0[l], d1[l]], np.uint32).view(np.uint8))
+        w.vm_q.append(None)
+
     def x_s_load_dword(self, w, i):
         self._sload(w, i, 1)
 
@@ -709,7 +731,7 @@ class Workgroup:
             vaddr, rsrc, soff = i.ops
             addrs, ok = self._buf_addrs(w, i, vaddr, rsrc, soff, 16)
             m0 = int(w.s[124])
-            assert m0 < 65536 and m0 % 16 == 0, f"LDS-DMA base {m0}"
+            assert m0 % 16 == 0, f"LDS-DMA base {m0}"
             dst0 = m0 + int(i.mods.get("offset", 0))
             data = np.zeros((64, 16), np.uint8)
             for l in range(64):

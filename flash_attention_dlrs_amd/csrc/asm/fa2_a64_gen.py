@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
-"""Generator of the gfx950 assembly kernel `fa2_fwd_a64_<dtype>_<c|n>` -- FA-2 forward, d = 128, f16 / bf16.
+"""Generator of the gfx950 assembly kernels `fa2_fwd_a64_<dtype>_<c|n>` -- FA-2 forward, d = 128, f16 / bf16.
 
 Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108 (exp2-domain online softmax in fp32, P rounded
 RTNE to the I/O dtype before P.V, O /= l once at the end, L = m + log2 l), as in fa2_mfma16h.hip.
 
 Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent structure"):
   * workgroup = 4 waves = one 256-row Q block; a wave owns two 32-row query blocks (qb = 0, 1) and the WHOLE 512-entry
-    register file: O^T in a[0:127], Q in a[128:191], the current K tile in a[192:255]; two score buffers, the V^T
-    fragments and the softmax state in the arch VGPRs;
+    register file: O^T in a[0:127], Q in a[128:191], the V^T fragments in a[192:255]; two score buffers, the current
+    K tile and the softmax state in the arch VGPRs;
   * swapped products: S^T[key][query] = K.Q^T, O^T[d][query] += V^T.P^T on v_mfma_f32_32x32x16 -- a lane owns one query
     row per query block, P never leaves the registers (the S accumulator, packed in place, is the B operand of P.V);
-  * 64-key K/V tiles arrive by LDS-DMA (buffer_load ... lds) into two K and two V buffers; LDS image = 8-row x 32-column
-    subtiles of 512 B with the 16-byte slots XOR-swizzled (T10 image (a)): row reads (ds_read_b128) and transposed reads
-    (ds_read_b64_tr_b16) are conflict-free and need two per-lane base registers each, everything else is an immediate;
-  * per tile two phases of 32 MFMAs:   A(t) = QK^T(t+1) || finish-softmax(t) (exp2, row sums, cvt) || V(t) tr-reads
-                                       B(t) = P.V(t)    || start-softmax(t+1) (row max, decision, s*c - m) || K(t+2) reads
-                                                        || LDS-DMA of V(t+2), K(t+3)
-    with ONE barrier per tile (between A and B); the loop is unrolled over the buffer parity;
+  * 64-key K/V tiles arrive by LDS-DMA (buffer_load ... lds) into rings of FOUR K and four V buffers; LDS image = 8-row x
+    32-column subtiles of 512 B with the 16-byte slots XOR-swizzled (T10 image (a)): row reads (ds_read_b128) and
+    transposed reads (ds_read_b64_tr_b16) are conflict-free and need two per-lane base registers each, the rest is an
+    immediate;
+  * per tile t two phases of 32 MFMAs:  A(t) = QK^T(t+1) || finish-softmax(t) (exp2, row sums, cvt) || V(t) tr-reads
+                                        B(t) = P.V(t)    || start-softmax(t+1) (row max, decision, s*c - m) || K(t+2) reads
+                                                         || LDS-DMA of V(t+3), K(t+4)
+    ONE barrier per tile (between A and B) behind a COUNTED `s_waitcnt vmcnt(8)`: a tile's DMA pieces have two tile steps
+    to land.  The loop body is four tiles (buffer indices and score-buffer parity are immediates);
+  * the tile stream is CONTINUOUS across jobs: every job has a multiple of four tiles, and its last body (the "seam")
+    already streams the next job's K(0..3), V(0..2) and Q rows and computes its first QK^T; only the epilogue (O through
+    the wave's LDS slice, L) sits between two jobs;
   * persistent grid: a workgroup walks its jobs (non-causal: one Q block; causal: the pair (nq-1-u, u)).
 
-The instruction stream is built as isa.Inst objects: printed to a .s file for the assembler, and executed by emu.py in the
-CPU test-suite (tests/test_asm_emu.py) against the oracle.
+The instruction stream is built as isa.Inst objects: printed to a .s file for the assembler, checked by check.py (wait
+states) and executed by emu.py in the CPU test-suite (tests/test_asm_emu.py) against an fp64 reference.
 """
 from __future__ import annotations
 
@@ -34,13 +39,13 @@ from .isa import A, EXEC, I, Inst, Label, M0, Reg, S, V, VCC, comment, label, wa
 SBUF = (0, 64)            # two score buffers of 64 registers: group g = 2*qb + kb at +16 g
 VF = 128                  # V^T fragments: (kstep, db) at VF + 4 * (4 * kstep + db)
 V_KRE, V_KRO = 192, 193   # K row-read lane bases (even / odd k-step)
-V_VR0, V_VR1 = 194, 195   # V transposed-read lane bases (u = 0 / 1)
+V_VR0, V_VR1 = 194, 195   # V transposed-read lane bases (u = 0 / 1), the V ring's LDS offset included
 V_DKO, V_DVO = 196, 197   # LDS-DMA per-lane source offsets (K / V row stride)
 V_MC = (198, 199)         # running row maximum in the exp2 domain (c * max), per query block
 V_RS = ((200, 201), (202, 203))  # row-sum accumulators [qb][2]
 V_MX = ((204, 205), (206, 207))  # row-max chains [qb][kb]
 V_CO = (208, 209)         # rescale coefficient per query block
-V_T = tuple(range(210, 220))     # temporaries
+V_T = tuple(range(210, 220))     # temporaries (V_T[2] = v212 is 4-aligned: a zero MFMA operand in the epilogue)
 V_QOFF = 220              # Q load lane offset (row stride qs_n)
 V_LANE = 221
 V_EW = 222                # epilogue LDS write base (row i, +8h)
@@ -48,8 +53,13 @@ V_ESW = 223               # epilogue swizzle term swz(i)
 V_ER = 224                # epilogue LDS read base
 V_EO = 225                # epilogue global store lane offset (os_n)
 V_L2 = 226                # L store lane offset
-V_TRI = 232               # causal: 16 registers, 0 / -inf triangle of a diagonal 32 x 32 block (lane = query)
-V_NINF = 248              # causal: one register of -inf (C operand blocks are built on the fly)
+V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), accumulators [4] (228..231)
+V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
+V_LSV = (234, 235)        # row sums of the finished job, saved for its epilogue
+V_MSV = (236, 237)        # running maximum of the finished job
+V_IMH = 238               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
+V_NINF = 239              # causal: -inf
+
 
 # AGPRs
 def A_O(qb, db):
@@ -61,48 +71,55 @@ def A_Q(qb, ks):
 
 
 def A_K(kb, ks):
-    return A(192 + (kb * 8 + ks) * 4, 4)
+    # the K tile lives in ARCH VGPRs v[128:191]: ds_read into accumulator registers while MFMAs write accumulators was
+    # measured 470 cycles per tile slower (and skews the four waves at the barrier)
+    return V(VF + (kb * 8 + ks) * 4, 4)
 
 
 def V_F(kstep, db):
-    return V(VF + 4 * (4 * kstep + db), 4)
+    # V^T fragments in a[192:255]: read in phase A, whose MFMAs (QK^T) write arch VGPRs
+    return A(192 + 4 * (4 * kstep + db), 4)
 
 
-# SGPRs
+# SGPRs.  s4..s47 hold the kernel arguments (loaded once).
 S_KARG = S(0, 2)
 S_WGID = S(2)
+S_FINAL = S(3)
 S_Q, S_K, S_V, S_O, S_L = S(4, 2), S(6, 2), S(8, 2), S(10, 2), S(12, 2)
 S_QSB, S_QSH, S_KSB, S_KSH, S_VSB, S_VSH, S_OSB, S_OSH, S_LSB, S_LSH = (S(14 + 2 * k, 2) for k in range(10))
 S_QSN, S_KSN, S_VSN, S_OSN = S(34), S(35), S(36), S(37)
 S_N, S_H, S_NQ, S_TOTAL = S(38), S(39), S(40), S(41)
 S_C, S_THR, S_NUNIT, S_G = S(42), S(43), S(44), S(45)
 S_NBH, S_NWG = S(46), S(47)
-S_KRS, S_VRS, S_QRS, S_ORS, S_LRS = S(48, 4), S(52, 4), S(56, 4), S(60, 4), S(64, 4)
+S_KRS, S_VRS, S_NVRS, S_SQ = S(48, 4), S(52, 4), S(56, 4), S(60, 4)   # K / V descriptors, the next job's V, a scratch one
+S_NB, S_NHH, S_NQI, S_NNT = S(64), S(65), S(66), S(67)                # the next job
 S_JOB, S_WAVE = S(68), S(69)
-S_KDMA, S_VDMA = S(70), S(71)
-S_K32, S_K32P, S_V32, S_V32P = S(72), S(73), S(74), S(75)
+S_KDMA, S_VDMA = S(70), S(71)    # source offset of the next K / V tile to stream (the wave's row base included)
+S_K32, S_V32 = S(72), S(74)      # 32 rows of K / V in bytes
 S_K64, S_V64 = S(76), S(77)
-S_LDSW = S(78)
+S_LDSW = S(78)                   # 2048 * wave: the wave's piece offset inside a ring buffer
 S_LOOP, S_FLAG = S(79), S(80)
-S_QI, S_BH, S_B, S_HH, S_UNIT, S_PASS = S(81), S(82), S(83), S(84), S(85), S(86)
+S_QI, S_B, S_HH, S_UNIT, S_PASS, S_NT = S(81), S(83), S(84), S(85), S(86), S(87)   # the current job
 S_T = tuple(S(88 + k) for k in range(8))  # temporaries s88..s95 (S_T[0] even: usable as a 64-bit pair)
-S_NT = S(87)       # tiles of this job
-S_QROW = (S(96), S(97))  # first row of the wave's query block qb
+S_QROW = (S(96), S(97))          # first row of the wave's query block qb (current job)
 S_DBG = S(98, 2)
-S_DIAG = S(100)    # causal: first diagonal tile of this job (tile index), per wave relation computed on the fly
-S_KMAX = S(101)    # K DMA offset of the job's last tile (the look-ahead is clamped to it)
+S_KW, S_VW = S(100), S(101)      # 8 * wave * row stride: the wave's row base inside a tile
+S_X0, S_X1 = S(73), S(75)        # spare
+S_X2 = S(82)
 
 # LDS map (bytes)
-KB = (0, 16384)
-VB = (32768, 49152)
-EPI = 65536        # + 16384 * wave: the wave's 64 x 256-byte output slice
-LDS_TOTAL = 131072
+KB = (0, 16384, 32768, 49152)
+VBASE = 65536
+VB = (0, 16384, 32768, 49152)    # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
+EPI = 131072                     # + 8192 * wave: the wave's 32 x 256-byte output slice (one query block at a time)
+LDS_TOTAL = 163840
 
 KARG_SIZE = 184
+NSLOT = 16
 
 
 class Gen:
-    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, dbg=False):
+    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=()):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
@@ -113,7 +130,8 @@ class Gen:
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
-        self.dbg = dbg
+        self.abl = set(abl)    # timing-only ablations of the steady loop (diagnostic builds; results wrong by construction)
+        self.stamps = stamps   # diagnostic build: s_memtime stamps of the job timeline go to the debug buffer
 
     # ------------------------------------------------------------------ small helpers
     def e(self, *insts):
@@ -126,6 +144,34 @@ class Gen:
     def lab(self, stem):
         self.uid += 1
         return f".L{self.name}_{stem}_{self.uid}"
+
+    def stamp(self, slot, real=False):
+        """diagnostic builds only: dbg[(wg * 4 + wave) * NSLOT + slot] = s_memtime (or s_memrealtime)"""
+        if not self.stamps:
+            return []
+        t = S(S_T[0].idx, 2)
+        v = V(V_T[8], 2)
+        return [I("s_memrealtime" if real else "s_memtime", t), waitcnt(lgkmcnt=0),
+                I("v_mov_b32", v.sub(0), t.sub(0)), I("v_mov_b32", v.sub(1), t.sub(1)),
+                I("v_mov_b32", V(V_T[7]), 0), I("global_store_dwordx2", V(V_T[7]), v, S_DBG, offset=8 * slot)]
+
+    def stamp_acc(self, k):
+        """diagnostic builds only: acc[k] += cycles since the previous stamp_acc"""
+        if not self.stamps:
+            return []
+        t = S(S_T[0].idx, 2)
+        tmp = V(V_T[9])
+        return [I("s_memtime", t), waitcnt(lgkmcnt=0), I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)),
+                I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp), I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
+
+    def stamp_flush(self):
+        if not self.stamps:
+            return []
+        out = [I("v_mov_b32", V(V_T[7]), 0)]
+        for k in range(4):
+            out += [I("global_store_dword", V(V_T[7]), V(V_ST_ACC + k), S_DBG, offset=8 * (10 + k)),
+                    I("v_mov_b32", V(V_ST_ACC + k), 0)]
+        return out
 
     def udiv(self, q: Reg, r: Reg | None, n: Reg, d: Reg):
         """q = n / d, r = n % d for wave-uniform 32-bit values < 2^22 (float reciprocal + one correction each way)"""
@@ -146,13 +192,17 @@ class Gen:
     def mad64(self, dst: Reg, idx: Reg, stride: Reg):
         """dst(64) += idx(32, unsigned) * stride(64)"""
         lo, hi = S_T[6], S_T[7]
-        self.e(I("s_mul_i32", lo, idx, stride.sub(0)), I("s_mul_hi_u32", hi, idx, stride.sub(0)),
-               I("s_add_u32", dst.sub(0), dst.sub(0), lo), I("s_addc_u32", dst.sub(1), dst.sub(1), hi),
-               I("s_mul_i32", lo, idx, stride.sub(1)), I("s_add_u32", dst.sub(1), dst.sub(1), lo))
+        return [I("s_mul_i32", lo, idx, stride.sub(0)), I("s_mul_hi_u32", hi, idx, stride.sub(0)),
+                I("s_add_u32", dst.sub(0), dst.sub(0), lo), I("s_addc_u32", dst.sub(1), dst.sub(1), hi),
+                I("s_mul_i32", lo, idx, stride.sub(1)), I("s_add_u32", dst.sub(1), dst.sub(1), lo)]
 
-    def make_rsrc(self, rs: Reg, base: Reg):
-        self.e(I("s_mov_b32", rs.sub(0), base.sub(0)), I("s_and_b32", rs.sub(1), base.sub(1), 0xFFFF),
-               I("s_mov_b32", rs.sub(2), 0x7FFFFFF0), I("s_mov_b32", rs.sub(3), 0x00020000))
+    def make_desc(self, rs: Reg, base: Reg, sb: Reg, sh: Reg, b: Reg, hh: Reg):
+        """raw buffer descriptor of the (b, hh) slice of a tensor: base + b * sb + hh * sh (the range check is not used:
+        soffset is unchecked anyway; every address the kernel forms lies inside the tensor, N being a multiple of 256)"""
+        tmp = S(S_T[0].idx, 2)
+        return ([I("s_mov_b64", tmp, base)] + self.mad64(tmp, b, sb) + self.mad64(tmp, hh, sh) +
+                [I("s_mov_b32", rs.sub(0), tmp.sub(0)), I("s_and_b32", rs.sub(1), tmp.sub(1), 0xFFFF),
+                 I("s_mov_b32", rs.sub(2), 0x7FFFFFF0), I("s_mov_b32", rs.sub(3), 0x00020000)])
 
     # ------------------------------------------------------------------ kernel prologue: arguments, lane constants
     def k_setup(self):
@@ -177,7 +227,7 @@ class Gen:
           I("v_lshl_add_u32", V(V_KRE), t2, 4, t1),
           I("v_xor_b32", t2, 2, t2),                       # (2 + h) ^ g
           I("v_lshl_add_u32", V(V_KRO), t2, 4, t1))
-        # ---- V transposed-read bases: 64 (4 h + q) + 16 ((2 w + (p >> 1)) ^ ((2 u + h) & 3)) + 8 (p & 1)
+        # ---- V transposed-read bases: VBASE + 64 (4 h + q) + 16 ((2 w + (p >> 1)) ^ ((2 u + h) & 3)) + 8 (p & 1)
         #      w = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3
         e(comment("V transposed-read lane bases"),
           I("v_bfe_u32", t0, lane, 2, 2),                  # q
@@ -185,6 +235,7 @@ class Gen:
           I("v_lshl_add_u32", t0, t3, 2, t0),              # 4 h + q
           I("v_lshlrev_b32", t0, 6, t0),                   # 64 (4 h + q)
           I("v_and_b32", t1, 1, lane), I("v_lshl_add_u32", t0, t1, 3, t0),  # + 8 (p & 1)
+          I("v_add_u32", t0, VBASE, t0),
           I("v_bfe_u32", t1, lane, 4, 1), I("v_lshlrev_b32", t1, 1, t1),    # 2 w
           I("v_bfe_u32", t2, lane, 1, 1), I("v_or_b32", t1, t1, t2),        # 2 w + (p >> 1)
           I("v_xor_b32", t2, t1, t3),                      # u = 0: ^ h
@@ -203,14 +254,14 @@ class Gen:
           I("v_lshlrev_b32", t0, 4, t0),                   # 16 chunk
           I("v_bfe_u32", t1, lane, 2, 3))                  # row_in
         e(waitcnt(lgkmcnt=0, comment="kernel arguments are in"))
-        e(I("v_mul_lo_u32", t2, t1, S_KSN), I("v_add_u32", V(V_DKO), t2, t0),
-          I("v_mul_lo_u32", t2, t1, S_VSN), I("v_add_u32", V(V_DVO), t2, t0))
+        e(I("v_mul_lo_u32", t2, t1, S_KSN), I("v_add_u32", V(V_DKO), t2, t0), I("v_add_u32", V(V_DKO2), 128, V(V_DKO)),
+          I("v_mul_lo_u32", t2, t1, S_VSN), I("v_add_u32", V(V_DVO), t2, t0), I("v_add_u32", V(V_DVO2), 128, V(V_DVO)))
         # ---- Q load lane offset: i * qs_n + 16 h
         e(comment("Q load / epilogue lane constants"),
           I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane),
           I("v_mul_lo_u32", t1, t0, S_QSN), I("v_lshl_add_u32", V(V_QOFF), t3, 4, t1))
-        # ---- epilogue: write base EPI + 16384 wave + 256 i + 8 h; swizzle term (((i & 3) << 2) | ((i >> 2) & 3)) << 4
-        e(I("s_lshl_b32", S_T[0], S_WAVE, 14), I("s_add_u32", S_T[0], S_T[0], EPI),
+        # ---- epilogue: write base EPI + 8192 wave + 256 i + 8 h; swizzle term ((i & 3) << 2) | ((i >> 2) & 3)
+        e(I("s_lshl_b32", S_T[0], S_WAVE, 13), I("s_add_u32", S_T[0], S_T[0], EPI),
           I("v_lshlrev_b32", t1, 8, t0), I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1),
           I("v_and_b32", t1, 3, t0), I("v_lshlrev_b32", t1, 2, t1), I("v_bfe_u32", t2, t0, 2, 2), I("v_or_b32", t1, t1, t2),
           I("v_mov_b32", V(V_ESW), t1))
@@ -220,97 +271,117 @@ class Gen:
           I("v_lshl_add_u32", t2, t0, 8, t2), I("v_add_u32", V(V_ER), S_T[0], t2),
           I("v_mul_lo_u32", t2, t0, S_OSN), I("v_lshl_add_u32", V(V_EO), t1, 4, t2),
           I("v_and_b32", t0, 31, lane), I("v_lshlrev_b32", V(V_L2), 1, t0))
+        if self.stamps:
+            e(I("s_lshl_b32", S_T[0], S_WGID, 2), I("s_add_u32", S_T[0], S_T[0], S_WAVE), I("s_mul_i32", S_T[0], S_T[0], 8 * NSLOT),
+              I("s_add_u32", S_DBG.sub(0), S_DBG.sub(0), S_T[0]), I("s_addc_u32", S_DBG.sub(1), S_DBG.sub(1), 0))
+            e(self.stamp(6, real=True), self.stamp(8))
+            e([I("v_mov_b32", V(V_ST_ACC + k), 0) for k in range(4)], I("v_mov_b32", V(V_ST_LAST), 0))
         # ---- scalar constants
-        e(I("s_lshl_b32", S_K32, S_KSN, 5), I("s_add_u32", S_K32P, S_K32, 128),
-          I("s_lshl_b32", S_V32, S_VSN, 5), I("s_add_u32", S_V32P, S_V32, 128),
+        e(I("s_lshl_b32", S_K32, S_KSN, 5), I("s_lshl_b32", S_V32, S_VSN, 5),
           I("s_lshl_b32", S_K64, S_KSN, 6), I("s_lshl_b32", S_V64, S_VSN, 6),
-          I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0),
+          I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
+          I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
         if self.causal:
-            # triangle block: register r <-> key (r & 3) + 8 (r >> 2) + 4 h of a 32-key block, lane <-> query i: -inf where key > i
-            e(comment("causal: diagonal-block mask (0 / -inf) as an MFMA C operand"),
+            e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
-              I("v_sub_u32", t0, t0, t3),   # i - 4 h
+              I("v_sub_u32", V(V_IMH), t0, t3),   # i - 4 h
               I("v_mov_b32", V(V_NINF), float("-inf")))
-            for r in range(16):
-                key = (r & 3) + 8 * (r >> 2)
-                e(I("v_cmp_lt_i32", VCC, t0, key), I("v_cndmask_b32", V(V_TRI + r), 0, V(V_NINF), VCC))
 
-    # ------------------------------------------------------------------ job decode -> S_BH, S_UNIT (then S_QI by the caller)
-    def k_decode(self):
+    # ------------------------------------------------------------------ job decode: S_JOB (+ S_PASS) -> S_NB, S_NHH, S_NQI, S_NNT
+    def k_decode_next(self):
         e = self.e
         l_else, l_done = self.lab("dec_else"), self.lab("dec_done")
         t = S_T
-        e(comment("job index -> (b, h) and work unit"),
+        bh = S_X2
+        e(comment("job index -> (b, h), work unit, query block, tile count of the NEXT job"),
           I("s_and_b32", t[0], S_NBH, 7), I("s_cmp_lg_u32", t[0], 0), I("s_cbranch_scc1", Label(l_else)))
         # slot = id >> 3; GN = G * nunit; batch = slot / GN; r = slot % GN; bh = (batch * G + r % G) * 8 + (id & 7); unit = r / G
         e(I("s_lshr_b32", t[0], S_JOB, 3), I("s_mul_i32", t[1], S_G, S_NUNIT))
         self.udiv(t[2], t[3], t[0], t[1])       # batch, r
         self.udiv(S_UNIT, t[4], t[3], S_G)      # unit = r / G, r % G
         e(I("s_mul_i32", t[2], t[2], S_G), I("s_add_u32", t[2], t[2], t[4]), I("s_lshl_b32", t[2], t[2], 3),
-          I("s_and_b32", t[0], S_JOB, 7), I("s_add_u32", S_BH, t[2], t[0]), I("s_branch", Label(l_done)))
+          I("s_and_b32", t[0], S_JOB, 7), I("s_add_u32", bh, t[2], t[0]), I("s_branch", Label(l_done)))
         e(label(l_else))
-        self.udiv(S_BH, S_UNIT, S_JOB, S_NUNIT)
+        self.udiv(bh, S_UNIT, S_JOB, S_NUNIT)
         e(label(l_done))
-        self.udiv(S_B, S_HH, S_BH, S_H)
-
-    # ------------------------------------------------------------------ per-job scalars, descriptors, first loads
-    def dma_piece(self, rsrc, vlane, soff_base, piece, lds_const, strides32):
-        """one 1-KiB LDS-DMA piece.  piece j in 0..3: rows R = wave, wave + 4; halves 0 / 1"""
-        s32, s32p = strides32
-        out = []
-        if piece == 0:
-            so = soff_base
+        self.udiv(S_NB, S_NHH, bh, S_H)
+        if self.causal:
+            # unit u, pass 0: qi = nq - 1 - u (heavy), pass 1: qi = u;  tiles = 4 (qi + 1)
+            l_p1, l_pd = self.lab("pass1"), self.lab("passd")
+            e(I("s_cmp_lg_u32", S_PASS, 0), I("s_cbranch_scc1", Label(l_p1)),
+              I("s_sub_u32", S_NQI, S_NQ, 1), I("s_sub_u32", S_NQI, S_NQI, S_UNIT), I("s_branch", Label(l_pd)),
+              label(l_p1), I("s_mov_b32", S_NQI, S_UNIT), label(l_pd),
+              I("s_add_u32", t[0], S_NQI, 1), I("s_lshl_b32", S_NNT, t[0], 2))
         else:
+            e(I("s_mov_b32", S_NQI, S_UNIT), I("s_lshr_b32", S_NNT, S_N, 6))
+
+    def k_advance(self):
+        """S_JOB / S_PASS -> the job after the most recently decoded one, decoded into the next-job registers;
+        S_FINAL = 1 if there is none (the next-job registers then repeat the current job)"""
+        e = self.e
+        l_fin, l_ok = self.lab("adv_final"), self.lab("adv_ok")
+        if self.causal:
+            l_adv = self.lab("adv")
+            # pass 0 -> pass 1 of the same unit unless the pair is a single tile (nq odd, middle)
+            e(I("s_cmp_lg_u32", S_PASS, 0), I("s_cbranch_scc1", Label(l_adv)),
+              I("s_sub_u32", S_T[0], S_NQ, 1), I("s_sub_u32", S_T[0], S_T[0], S_UNIT), I("s_cmp_eq_u32", S_T[0], S_UNIT),
+              I("s_cbranch_scc1", Label(l_adv)),
+              I("s_mov_b32", S_PASS, 1), I("s_branch", Label(l_ok)),
+              label(l_adv), I("s_mov_b32", S_PASS, 0), I("s_add_u32", S_JOB, S_JOB, S_NWG))
+        else:
+            e(I("s_add_u32", S_JOB, S_JOB, S_NWG))
+        e(I("s_cmp_ge_u32", S_JOB, S_TOTAL), I("s_cbranch_scc1", Label(l_fin)), label(l_ok))
+        self.k_decode_next()
+        l_done = self.lab("adv_done")
+        e(I("s_branch", Label(l_done)), label(l_fin),
+          comment("no further job: the seam streams the current job's first tiles again (results discarded)"),
+          I("s_mov_b32", S_FINAL, 1), I("s_mov_b32", S_NB, S_B), I("s_mov_b32", S_NHH, S_HH), I("s_mov_b32", S_NQI, S_QI),
+          I("s_mov_b32", S_NNT, S_NT), label(l_done))
+
+    def k_promote(self):
+        """next job -> current job"""
+        self.e(I("s_mov_b32", S_B, S_NB), I("s_mov_b32", S_HH, S_NHH), I("s_mov_b32", S_QI, S_NQI), I("s_mov_b32", S_NT, S_NNT),
+               # query rows of this wave: qrow[qb] = 256 qi + 64 wave + 32 qb
+               I("s_lshl_b32", S_T[0], S_QI, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_QROW[0], S_T[0], S_T[1]),
+               I("s_add_u32", S_QROW[1], S_QROW[0], 32))
+
+    # ------------------------------------------------------------------ LDS-DMA
+    def dma_piece(self, which, piece, buf):
+        """one 1-KiB LDS-DMA piece of the next K / V tile into ring buffer `buf`.  piece j: rows 8 R .. 8 R + 7 with
+        R = wave (j < 2) or wave + 4, 128-byte half j & 1 (the +128 rides in the second lane-offset register)"""
+        if which == "k":
+            rsrc, vl, vl2, base, s32, lds0 = S_KRS, V(V_DKO), V(V_DKO2), S_KDMA, S_K32, KB[buf]
+        else:
+            rsrc, vl, vl2, base, s32, lds0 = S_VRS, V(V_DVO), V(V_DVO2), S_VDMA, S_V32, VBASE + VB[buf]
+        out = []
+        so = base
+        if piece >= 2:
             so = S_T[5]
-            out.append(I("s_add_u32", so, soff_base, (128, s32, s32p)[piece - 1]))
-        out.append(I("s_add_u32", M0, S_LDSW, lds_const + (0, 1024, 8192, 9216)[piece]))
+            out.append(I("s_add_u32", so, base, s32))
+        out.append(I("s_add_u32", M0, S_LDSW, lds0 + (0, 1024, 8192, 9216)[piece]))
         out.append(I("s_nop", 0))
-        out.append(I("buffer_load_dwordx4", vlane, rsrc, so, offen=1, lds=1))
+        out.append(I("buffer_load_dwordx4", vl2 if piece & 1 else vl, rsrc, so, offen=1, lds=1, tag=f"dma {which}{piece}"))
         return out
 
     def dma_tile(self, which, buf):
         out = []
         for j in range(4):
-            if which == "k":
-                out += self.dma_piece(S_KRS, V(V_DKO), S_KDMA, j, KB[buf], (S_K32, S_K32P))
-            else:
-                out += self.dma_piece(S_VRS, V(V_DVO), S_VDMA, j, VB[buf], (S_V32, S_V32P))
+            out += self.dma_piece(which, j, buf)
+        out.append(I("s_add_u32", S_KDMA, S_KDMA, S_K64) if which == "k" else I("s_add_u32", S_VDMA, S_VDMA, S_V64))
         return out
 
-    def k_job_setup(self):
-        """S_BH/S_B/S_HH/S_QI known: descriptors, query rows, tile count"""
-        e = self.e
-        e(comment("per-job bases and descriptors"))
-        for base, sb, sh, rs in ((S_K, S_KSB, S_KSH, S_KRS), (S_V, S_VSB, S_VSH, S_VRS), (S_Q, S_QSB, S_QSH, S_QRS),
-                                 (S_O, S_OSB, S_OSH, S_ORS), (S_L, S_LSB, S_LSH, S_LRS)):
-            tmp = S(S_T[0].idx, 2)
-            e(I("s_mov_b64", tmp, base))
-            self.mad64(tmp, S_B, sb)
-            self.mad64(tmp, S_HH, sh)
-            self.make_rsrc(rs, tmp)
-        # query rows of this wave: qrow[qb] = 256 qi + 64 wave + 32 qb
-        e(I("s_lshl_b32", S_T[0], S_QI, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_QROW[0], S_T[0], S_T[1]),
-          I("s_add_u32", S_QROW[1], S_QROW[0], 32))
-        if self.causal:
-            e(I("s_add_u32", S_T[0], S_QI, 1), I("s_lshl_b32", S_NT, S_T[0], 2))     # tiles = 4 (qi + 1)
-        else:
-            e(I("s_lshr_b32", S_NT, S_N, 6))
-        # wave's DMA row base: 8 * wave * stride
-        e(I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KDMA, S_T[0], S_KSN), I("s_mul_i32", S_VDMA, S_T[0], S_VSN),
-          I("s_sub_u32", S_T[0], S_NT, 1), I("s_mul_i32", S_T[0], S_T[0], S_K64), I("s_add_u32", S_KMAX, S_T[0], S_KDMA))
-
-    def k_job_first_loads(self):
-        e = self.e
-        e(comment("first loads of the job: K(0), V(0), K(1) by LDS-DMA, Q rows into a[128:191]"))
-        e(self.dma_tile("k", 0), self.dma_tile("v", 0))
-        e(I("s_add_u32", S_KDMA, S_KDMA, S_K64), I("s_add_u32", S_VDMA, S_VDMA, S_V64))
-        e(self.dma_tile("k", 1))
-        e(I("s_add_u32", S_KDMA, S_KDMA, S_K64))
+    def q_loads(self, b: Reg, hh: Reg, qi: Reg):
+        """Q rows of job (b, hh, qi) of this wave into a[128:191] (16 loads)"""
+        out = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh)
+        out += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_T[0], S_T[0], S_T[1])]
         for qb in range(2):
-            e(I("s_mul_i32", S_T[0], S_QROW[qb], S_QSN))
+            out += [I("s_mul_i32", S_T[1], S_T[0], S_QSN)]
             for ks in range(8):
-                e(I("buffer_load_dwordx4", A_Q(qb, ks), V(V_QOFF), S_QRS, S_T[0], offen=1, offset=32 * ks))
+                out.append(I("buffer_load_dwordx4", A_Q(qb, ks), V(V_QOFF), S_SQ, S_T[1], offen=1, offset=32 * ks, tag="qload"))
+            if qb == 0:
+                out += [I("s_add_u32", S_T[0], S_T[0], 32)]
+        return out
 
     # ------------------------------------------------------------------ the two phases
     def interleave(self, mfmas, fillers):
@@ -342,7 +413,7 @@ class Gen:
                 out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}"))
         return out
 
-    def pv_mfmas(self, X, first):
+    def pv_mfmas(self, X):
         """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep); P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s"""
         out = []
         for kstep in range(4):
@@ -350,12 +421,11 @@ class Gen:
             for db in range(4):
                 for qb in range(2):
                     p = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                    c = 0 if (first and kstep == 0) else A_O(qb, db)
-                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), p, c, tag=f"pv ks{kstep} db{db} qb{qb}"))
+                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), p, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}"))
         return out
 
     def v_reads(self, buf):
-        """32 transposed reads of V tile in VB[buf]: fragment (kstep, db) <- u = 0, 1"""
+        """32 transposed reads of the V tile in VB[buf]: fragment (kstep, db) <- u = 0, 1"""
         out = []
         for kstep in range(4):
             for db in range(4):
@@ -390,16 +460,19 @@ class Gen:
                 ops.append((el, ex, ad, cv))
         return ops
 
-    def phase_a(self, p, with_qk=True, with_finish=True, cinit=None):
-        """A(t), parity p = t & 1: QK^T(t+1) -> S[1-p]  ||  finish(S[p])  ||  V(t) reads from VB[p]"""
+    def phase_a(self, t4, with_qk=True, with_finish=True, cinit=None, steady=False):
+        """A(t), t4 = t & 3: QK^T(t+1) -> S[1-p]  ||  finish(S[p])  ||  V(t) reads from VB[t4]"""
+        p = t4 & 1
         X, Y = SBUF[p], SBUF[1 - p]
         mf = self.qk_mfmas(Y, cinit) if with_qk else []
         fill = []
+        abl = self.abl if steady else set()
         if with_finish:
-            vr = self.v_reads(p)
+            vr = self.v_reads(t4)
             for k, ins in enumerate(vr):           # 2 reads per gap over the first 16 gaps
-                fill.append((k * 0.5, [ins]))
-            fin = self.finish_ops(X, self.nexp_b)
+                if "novread" not in abl:
+                    fill.append((k * 0.5, [ins]))
+            fin = self.finish_ops(X, self.nexp_b) if "nofinish" not in abl else []
             n = len(fin)
             span = 31.0
             for k, (el, ex, ad, cv) in enumerate(fin):
@@ -410,58 +483,114 @@ class Gen:
                 if cv:
                     fill.append((pos + 1.4, cv))
         if not mf:
-            # no MFMAs (drain): plain sequence in position order
             return [x for _, ins in sorted(fill, key=lambda f: f[0]) for x in ins]
         return self.interleave(mf, fill)
 
     def max_ops(self, Y):
-        out = []  # list of (group, [insts])
+        """row-max chains of the four score groups, interleaved so that no instruction waits on its predecessor; group 3's
+        chain (whose MFMAs ended phase A) starts late (MFMA result -> VALU read needs 12 wait states)"""
+        chains = []
         for g in range(4):
             qb, kb = g >> 1, g & 1
             mx = V(V_MX[qb][kb])
-            y = lambda r: V(Y + 16 * g + r)
+            y = lambda r, g=g: V(Y + 16 * g + r)
             ops = [I("v_max3_f32", mx, y(0), y(1), y(2), tag=f"max g{g}")]
             for r in range(3, 15, 2):
                 ops.append(I("v_max3_f32", mx, mx, y(r), y(r + 1), tag=f"max g{g}"))
             ops.append(I("v_max_f32", mx, mx, y(15), tag=f"max g{g}"))
-            out.append((g, ops))
+            chains.append(ops)
+        out = []
+        idx = [0, 0, 0, 0]
+        while any(idx[g] < len(chains[g]) for g in range(4)):
+            for g in range(4):
+                if g == 3 and len(out) < 14 and any(idx[k] < len(chains[k]) for k in range(3)):
+                    continue
+                if idx[g] < len(chains[g]):
+                    out.append(chains[g][idx[g]])
+                    idx[g] += 1
         return out
 
-    def phase_b(self, p, with_pv=True, first_pv=False, with_start=True, init=False, with_kread=True, with_dma=True):
-        """B(t), parity p: P.V(t) from S[p]  ||  start-softmax(t+1) on S[1-p]  ||  K(t+2) reads from KB[p]
-        ||  LDS-DMA V(t+2) -> VB[p], K(t+3) -> KB[1-p].   init: first tile of a job (m := max, no decision)"""
+    def mask_block(self, Y, jd, cond=None):
+        """causal: the tile whose softmax starts in this phase B is diagonal tile jd (0..3) of its job: keys 64 jd .. 64 jd + 63 of
+        the 256-key diagonal span against this wave's rows 64 w .. 64 w + 63.  w > jd: nothing; w == jd: score groups
+        (qb0, kb0) and (qb1, kb1) get the triangle (key > query -> -inf), (qb0, kb1) is all -inf; w < jd: all -inf.
+        Register r of a group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i.  cond: (sgpr, value) extra run-time
+        condition (the tile is diagonal at all).  Returns the in-line test; the masking runs out of line."""
+        l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
+        out = []
+        if cond is not None:
+            out += [I("s_cmp_lg_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_back))]
+        out += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
+        if jd > 0:
+            out += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
+        out += [label(l_back)]
+        ninf = V(V_NINF)
+        blk = [label(l_eq), I("s_nop", 11)]   # the chain of group 3 ended with the last MFMA of phase A
+        for r in range(16):
+            key = (r & 3) + 8 * (r >> 2)
+            blk += [I("v_cmp_lt_i32", VCC, V(V_IMH), key),
+                    I("v_cndmask_b32", V(Y + r), V(Y + r), ninf, VCC), I("v_cndmask_b32", V(Y + 48 + r), V(Y + 48 + r), ninf, VCC),
+                    I("v_mov_b32", V(Y + 16 + r), ninf)]
+        blk += [I("s_branch", Label(l_back))]
+        self.ool.append(blk)
+        if jd > 0:
+            blk = [label(l_lt), I("s_nop", 11)]
+            blk += [I("v_mov_b32", V(Y + r), ninf) for r in range(64)]
+            blk += [I("s_branch", Label(l_back))]
+            self.ool.append(blk)
+        return out
+
+    def phase_b(self, t4, with_pv=True, with_start=True, init=False, with_kread=True, with_dma=True, steady=False,
+                save=False, pre=(), qload=None, mask=None):
+        """B(t), t4 = t & 3: P.V(t) from S[p]  ||  start-softmax(t+1) on S[1-p]  ||  K(t+2) reads from KB[(t+2) & 3]
+        ||  LDS-DMA V(t+3) -> VB[(t+3) & 3], K(t+4) -> KB[t4].
+        init: the tile started here is the first of a job (m := its row maximum, sums := 0, no decision)
+        save: this is the last tile of a job: its row sums and maximum are put aside for the epilogue
+        pre: instructions ahead of the phase (descriptor switches);  qload: the next job's Q loads, issued first"""
+        p = t4 & 1
         X, Y = SBUF[p], SBUF[1 - p]
-        mf = self.pv_mfmas(X, first_pv) if with_pv else []
+        mf = self.pv_mfmas(X) if with_pv else []
         fill = []
-        pre = []
+        head = list(pre)
         post = []
+        abl = self.abl if steady else set()
+        if "nokread" in abl:
+            with_kread = False
+        if "nostart" in abl:
+            with_start = False
+        if save:
+            for qb in range(2):
+                head += [I("v_add_f32", V(V_LSV[qb]), V(V_RS[qb][0]), V(V_RS[qb][1])), I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb]))]
+        if qload:
+            head += qload
+        if mask is not None:
+            head += self.mask_block(Y, *mask)
         if with_kread:
-            for k, ins in enumerate(self.k_reads(p)):
+            for k, ins in enumerate(self.k_reads((t4 + 2) & 3)):
                 fill.append((0.2 + k * 0.75, [ins]))
         if with_dma:
-            pieces = []
-            for j in range(4):
-                pieces.append(self.dma_piece(S_VRS, V(V_DVO), S_VDMA, j, VB[p], (S_V32, S_V32P)))
-            for j in range(4):
-                pieces.append(self.dma_piece(S_KRS, V(V_DKO), S_KDMA, j, KB[1 - p], (S_K32, S_K32P)))
+            pieces = [self.dma_piece("v", j, (t4 + 3) & 3) for j in range(4)] + [self.dma_piece("k", j, t4) for j in range(4)]
             for k, pc in enumerate(pieces):
-                fill.append((13.5 + 2.2 * k, pc))
-            post += [I("s_add_u32", S_VDMA, S_VDMA, S_V64), I("s_add_u32", S_KDMA, S_KDMA, S_K64), I("s_min_u32", S_KDMA, S_KDMA, S_KMAX)]
+                if "nodma" in abl:
+                    continue
+                fill.append((12.5 + 2.3 * k, pc))
+            post += [I("s_add_u32", S_VDMA, S_VDMA, S_V64), I("s_add_u32", S_KDMA, S_KDMA, S_K64)]
         if with_start:
             t0, t1 = V(V_T[0]), V(V_T[1])
-            mxs = self.max_ops(Y)
-            # groups 0..2 are long complete; group 3's chain ended with the last MFMA of phase A: keep it last
             pos = 0.0
-            for g, ops in mxs:
-                for ins in ops:
+            for ins in self.max_ops(Y):
+                if "nomax" not in abl:
                     fill.append((pos, [ins]))
-                    pos += 0.22
+                pos += 0.22
             pos = max(pos, 7.1)
             comb = []
             for qb in range(2):
                 a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
-                comb += [I("v_max_f32", a, a, b), I("v_mov_b32", b, a)]
-            comb += [I("s_nop", 1)]
+                comb += [I("v_max_f32", a, a, b)]
+            for qb in range(2):
+                a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
+                comb += [I("v_mov_b32", b, a)]
+            comb += [I("s_nop", 0)]
             for qb in range(2):
                 a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
                 comb += [I("v_permlane32_swap_b32", a, b)]
@@ -473,8 +602,6 @@ class Gen:
                     comb += [I("v_mul_f32", V(V_MC[qb]), S_C, V(V_MX[qb][0])),
                              I("v_mov_b32", V(V_RS[qb][0]), 0), I("v_mov_b32", V(V_RS[qb][1]), 0)]
                 fill.append((pos, comb))
-                for k in range(128):   # O^T := 0 (this phase has no MFMAs)
-                    fill.append((pos + 0.01, [I("v_accvgpr_write_b32", A(k), 0)]))
             else:
                 l_fire, l_back = self.lab("fire"), self.lab("fire_back")
                 comb += [I("v_fma_f32", t0, V(V_MX[0][0]), S_C, -V(V_MC[0])), I("v_fma_f32", t1, V(V_MX[1][0]), S_C, -V(V_MC[1])),
@@ -498,7 +625,8 @@ class Gen:
                 g = k >> 4
                 qb = g >> 1
                 y = V(Y + k)
-                fill.append((pos + k * span / nf, [I("v_fma_f32", y, y, S_C, -V(V_MC[qb]), tag=f"fma {k}")]))
+                if "nofma" not in abl:
+                    fill.append((pos + k * span / nf, [I("v_fma_f32", y, y, S_C, -V(V_MC[qb]), tag=f"fma {k}")]))
             # a few exp2 of the next finish phase ride here (phase A is the VALU-heavier one)
             for k in range(self.nexp_b):
                 y = V(Y + k)
@@ -507,7 +635,7 @@ class Gen:
             body = [x for _, ins in sorted(fill, key=lambda f: f[0]) for x in ins]
         else:
             body = self.interleave(mf, fill)
-        body = pre + body + post
+        body = head + body + post
         if with_start and not init:
             # deferred rescale of O and the row sums (rare)
             l_rs, l_back = self.lab("rescale"), self.lab("rescale_back")
@@ -525,152 +653,158 @@ class Gen:
             self.ool.append(blk)
         return body
 
-    def sync_mid(self):
-        return [waitcnt(vmcnt=0, lgkmcnt=0, comment="own DMA pieces landed; V fragments in"), I("s_barrier")]
+    def sync_mid(self, steady=False):
+        if steady and "novmwait" in self.abl:
+            return [waitcnt(lgkmcnt=0), I("s_barrier")]
+        if steady and "nobarrier" in self.abl:
+            return [waitcnt(vmcnt=8, lgkmcnt=0)]
+        return [waitcnt(vmcnt=8, lgkmcnt=0, comment="the DMA pieces of two steps ago have landed; V fragments in"), I("s_barrier")]
 
-    def step(self, p, **kw):
-        """one tile step of parity p"""
-        out = [comment(f"---- step parity {p}: phase A")]
+    def step(self, t4, a_pre=(), **kw):
+        """one tile step, t4 = t & 3"""
+        out = [comment(f"---- step {t4}: phase A")]
+        out += self.stamp_acc(2)
+        out += list(a_pre)
         out += [waitcnt(lgkmcnt=0, comment="K fragments in")]
-        out += self.phase_a(p, **{k: v for k, v in kw.items() if k in ("with_qk", "with_finish", "cinit")})
-        out += self.sync_mid()
-        out += [comment(f"---- step parity {p}: phase B")]
-        out += self.phase_b(p, **{k: v for k, v in kw.items() if k in ("with_pv", "first_pv", "with_start", "init", "with_kread", "with_dma")})
+        out += self.phase_a(t4, **{k: v for k, v in kw.items() if k in ("with_qk", "with_finish", "cinit", "steady")})
+        out += self.stamp_acc(0)
+        out += self.sync_mid(kw.get("steady", False))
+        out += self.stamp_acc(1)
+        out += [comment(f"---- step {t4}: phase B")]
+        out += self.phase_b(t4, **{k: v for k, v in kw.items()
+                                  if k in ("with_pv", "with_start", "init", "with_kread", "with_dma", "steady", "save", "pre", "qload", "mask")})
         return out
 
-    # ------------------------------------------------------------------ epilogue
+    # ------------------------------------------------------------------ epilogue of the current job
     def k_epilogue(self):
         e = self.e
         t = [V(x) for x in V_T]
-        e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global"))
-        e(I("s_nop", 15))  # last P.V MFMAs -> accumulator reads
+        e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global; O^T := 0"))
+        e(self.make_desc(S_SQ, S_L, S_LSB, S_LSH, S_B, S_HH))
+        e(I("s_nop", 7))  # last P.V MFMAs -> accumulator reads (the descriptor arithmetic above counts as well)
+        l = [t[0], t[3]]
+        m2 = [t[1], t[4]]
+        inv = [t[2], t[5]]
         for qb in range(2):
-            l, m2, inv = t[0 + 3 * qb], t[1 + 3 * qb], t[2 + 3 * qb]
-            e(I("v_add_f32", l, V(V_RS[qb][0]), V(V_RS[qb][1])), I("v_mov_b32", m2, l), I("s_nop", 1),
-              I("v_permlane32_swap_b32", l, m2), I("v_add_f32", l, l, m2),
-              I("v_rcp_f32", inv, l), I("v_log_f32", m2, l), I("s_nop", 0),
-              # one Newton step: inv += inv * (1 - l * inv)
-              I("v_fma_f32", l, -l, inv, 1.0), I("v_fma_f32", inv, l, inv, inv),
-              I("v_add_f32", m2, m2, V(V_MC[qb])))
+            e(I("v_mov_b32", l[qb], V(V_LSV[qb])), I("v_mov_b32", m2[qb], V(V_LSV[qb])))
+        e(I("s_nop", 1))
+        for qb in range(2):
+            e(I("v_permlane32_swap_b32", l[qb], m2[qb]))
+        for qb in range(2):
+            e(I("v_add_f32", l[qb], l[qb], m2[qb]))
+        for qb in range(2):
+            e(I("v_rcp_f32", inv[qb], l[qb]), I("v_log_f32", m2[qb], l[qb]))
+        e(I("s_nop", 0))
+        for qb in range(2):
+            # one Newton step: inv += inv * (1 - l * inv)
+            e(I("v_fma_f32", l[qb], -l[qb], inv[qb], 1.0), I("v_add_f32", m2[qb], m2[qb], V(V_MSV[qb])))
+        for qb in range(2):
+            e(I("v_fma_f32", inv[qb], l[qb], inv[qb], inv[qb]), I(self.cvt, m2[qb], m2[qb], m2[qb]))
         # L store (lanes 0..31), in the I/O dtype
         e(I("s_lshr_b64", EXEC, EXEC, 32))
         for qb in range(2):
-            m2 = t[1 + 3 * qb]
-            e(I(self.cvt, m2, m2, m2), I("s_lshl_b32", S_T[0], S_QROW[qb], 1),
-              I("buffer_store_short", m2, V(V_L2), S_LRS, S_T[0], offen=1))
+            e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), I("buffer_store_short", m2[qb], V(V_L2), S_SQ, S_T[0], offen=1))
         e(I("s_mov_b64", EXEC, -1))
-        # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row 32 qb + i, chunk 4 db + g4, +8 h)
+        e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH))
+        # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row i, chunk 4 db + g4, +8 h); one query block at a time.
+        # (S[0] already holds the next job's first scores and v[128:191] its K(1): the row registers are score buffer 1,
+        # whose P was consumed by the job's last P.V)
         tmp = [V(V_T[6]), V(V_T[7]), V(V_T[8]), V(V_T[9])]
         addr = V(V_MX[0][0])
+        addr2 = V(V_MX[0][1])
+        rows = [V(SBUF[1] + 4 * k, 4) for k in range(16)]
         for qb in range(2):
-            inv = t[2 + 3 * qb]
             for db in range(4):
                 for g4 in range(4):
                     src = A_O(qb, db)
                     e([I("v_accvgpr_read_b32", tmp[k], src.sub(4 * g4 + k)) for k in range(4)])
-                    e([I("v_mul_f32", tmp[k], tmp[k], inv) for k in range(4)])
+                    e(I("v_xor_b32", addr, 4 * db + g4, V(V_ESW)))
+                    e([I("v_mul_f32", tmp[k], tmp[k], inv[qb]) for k in range(4)])
+                    e(I("v_lshl_add_u32", addr, addr, 4, V(V_EW)))
                     e(I(self.cvt, tmp[0], tmp[0], tmp[1]), I(self.cvt, tmp[1], tmp[2], tmp[3]))
-                    e(I("v_xor_b32", addr, 4 * db + g4, V(V_ESW)), I("v_lshl_add_u32", addr, addr, 4, V(V_EW)))
-                    e(I("ds_write_b64", addr, V(tmp[0].idx, 2), offset=8192 * qb))
-        # read back whole rows and store: row 32 qb + 4 k + a
-        e(waitcnt(lgkmcnt=0))
-        rows = [V(SBUF[0] + 4 * k, 4) for k in range(16)]  # the score buffers are free now
-        idx = 0
-        for qb in range(2):
+                    e(I("ds_write_b64", addr, V(tmp[0].idx, 2)))
+            # read back whole rows: row 4 k + a
             for k in range(8):
                 if k & 3:
-                    e(I("v_xor_b32", addr, V(V_ER), (k & 3) << 4))
-                    src_a = addr
+                    e(I("v_xor_b32", addr2, V(V_ER), (k & 3) << 4))
+                    src_a = addr2
                 else:
                     src_a = V(V_ER)
-                e(I("ds_read_b128", rows[idx], src_a, offset=8192 * qb + 1024 * k))
-                idx += 1
-        idx = 0
-        for qb in range(2):
+                e(I("ds_read_b128", rows[8 * qb + k], src_a, offset=1024 * k))
             e(I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2))
             for k in range(8):
-                e(waitcnt(lgkmcnt=15 - idx))
-                e(I("buffer_store_dwordx4", rows[idx], V(V_EO), S_ORS, S_T[0], offen=1))
+                e(waitcnt(lgkmcnt=7 - k))
+                e(I("buffer_store_dwordx4", rows[8 * qb + k], V(V_EO), S_SQ, S_T[0], offen=1))
                 if k < 7:
                     e(I("s_add_u32", S_T[0], S_T[0], S_T[1]))
-                idx += 1
+        # O^T := 0 for the next job, on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
+        z = V(V_T[2], 4)
+        e([I("v_mov_b32", z.sub(k), 0) for k in range(4)], I("s_nop", 1))
+        for qb in range(2):
+            for db in range(4):
+                e(I(self.mfma, A_O(qb, db), z, z, 0))
 
     # ------------------------------------------------------------------ the whole kernel
     def build(self):
         e = self.e
         name = self.name
-        l_job, l_loop, l_tail, l_end, l_next = (f".L{name}_{s}" for s in ("job", "loop", "tail", "end", "next"))
+        l_job, l_loop, l_seam, l_end = (f".L{name}_{s}" for s in ("job", "loop", "seam", "end"))
         self.k_setup()
         e(I("s_cmp_ge_u32", S_JOB, S_TOTAL), I("s_cbranch_scc1", Label(l_end)))
-        e(label(l_job))
-        self.k_decode()
-        if self.causal:
-            # unit u, pass 0: qi = nq - 1 - u (heavy), pass 1: qi = u
-            l_p1, l_pd = self.lab("pass1"), self.lab("passd")
-            e(I("s_cmp_lg_u32", S_PASS, 0), I("s_cbranch_scc1", Label(l_p1)),
-              I("s_sub_u32", S_QI, S_NQ, 1), I("s_sub_u32", S_QI, S_QI, S_UNIT), I("s_branch", Label(l_pd)),
-              label(l_p1), I("s_mov_b32", S_QI, S_UNIT), label(l_pd))
-        else:
-            e(I("s_mov_b32", S_QI, S_UNIT))
-        self.k_job_setup()
-        self.k_job_first_loads()
+        # ---- first job of this workgroup: decode, descriptors, first loads, pipeline fill
+        self.k_decode_next()
+        self.k_promote()
+        e(comment("first job: K / V descriptors, K(0..2), V(0..1) by LDS-DMA, Q rows"))
+        e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH))
+        e(I("s_mov_b32", S_KDMA, S_KW), I("s_mov_b32", S_VDMA, S_VW))
+        e(self.stamp(0))
+        e(self.dma_tile("k", 0), self.dma_tile("v", 0), self.dma_tile("k", 1), self.dma_tile("v", 1), self.dma_tile("k", 2))
+        e(self.q_loads(S_B, S_HH, S_QI))
+        e([I("v_accvgpr_write_b32", A(k), 0) for k in range(128)])   # O^T := 0
         e(waitcnt(vmcnt=0), I("s_barrier"))
-        # K(0) -> registers
+        e(self.stamp(1))
         e(self.k_reads(0))
-        # step -1 (parity 1): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(1), K(2)
-        e(self.step(1, with_qk=True, with_finish=False, with_pv=False, init=True, cinit=self.cinit_for(0) if self.causal else None))
-        # main loop over tile pairs (t, t+1), t = 0, 2, .. NT - 4
-        e(I("s_sub_u32", S_LOOP, S_NT, 2), I("s_lshr_b32", S_LOOP, S_LOOP, 1))
-        if self.causal:
-            # the last two pairs (tiles NT-4 .. NT-1) are the diagonal: the steady loop covers t < NT - 4
-            e(I("s_sub_u32", S_LOOP, S_LOOP, 1))
-        e(I("s_cmp_eq_u32", S_LOOP, 0), I("s_cbranch_scc1", Label(l_tail)))
+        # step -1 (buffers as t4 = 3): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(2), K(3)
+        e(self.step(3, with_qk=True, with_finish=False, with_pv=False, init=True, mask=(0, (S_NT, 4)) if self.causal else None))
+        e(self.stamp(2), self.stamp_flush(), self.stamp_acc(3))
+        # ---- job loop
+        e(label(l_job))
+        e(I("s_lshr_b32", S_LOOP, S_NT, 2), I("s_sub_u32", S_LOOP, S_LOOP, 1),
+          I("s_cmp_eq_u32", S_LOOP, 0), I("s_cbranch_scc1", Label(l_seam)))
         e(label(l_loop))
-        first = True
-        # first_pv: the very first P.V of a job initialises O (C = 0): handled by peeling -- the loop body uses C = O, so O is
-        # zeroed explicitly at job start instead (cheap: 128 v_accvgpr_write would cost more than the MFMA C = 0 form; we peel)
-        e(self.step(0), self.step(1))
+        for t4 in range(4):
+            # causal: the last steady body starts the job's first diagonal tile in its last phase B
+            e(self.step(t4, steady=True, mask=(0, (S_LOOP, 1)) if self.causal and t4 == 3 else None))
         e(I("s_sub_u32", S_LOOP, S_LOOP, 1), I("s_cmp_lg_u32", S_LOOP, 0), I("s_cbranch_scc1", Label(l_loop)))
-        e(label(l_tail))
-        if self.causal:
-            self.k_causal_diag()
-        else:
-            e(self.step(0, with_kread=False, with_dma=False))
-            e(self.step(1, with_qk=False, with_start=False, with_kread=False, with_dma=False))
+        e(label(l_seam))
+        e(self.stamp(3), self.stamp_acc(2), self.stamp_flush())
+        # ---- the job's last four tiles: the next job's K / V / Q stream in, its first QK^T and softmax start run here
+        self.k_advance()
+        cm = self.causal
+        if True:
+            kpre = self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_NB, S_NHH) + [I("s_mov_b32", S_KDMA, S_KW)] + \
+                self.make_desc(S_NVRS, S_V, S_VSB, S_VSH, S_NB, S_NHH)
+            e(self.step(0, pre=kpre, mask=(1,) if cm else None))        # K(t+4) = next job's K(0)
+            vpre = [I("s_mov_b32", S_VRS.sub(k), S_NVRS.sub(k)) for k in range(4)] + [I("s_mov_b32", S_VDMA, S_VW)]
+            e(self.step(1, pre=vpre, mask=(2,) if cm else None))        # V(t+3) = next job's V(0)
+            e(self.step(2, qload=self.q_loads(S_NB, S_NHH, S_NQI), mask=(3,) if cm else None))   # Q rows of the next job (Q was last read in this step's A)
+            e(self.step(3, a_pre=[waitcnt(vmcnt=8, comment="Q rows of the next job are in")], init=True, save=True,
+                        mask=(0, (S_NNT, 4)) if cm else None))           # the next job's tile 0 is diagonal if it has only four
+        e(self.stamp(4))
         self.k_epilogue()
-        # next job
-        if self.causal:
-            l_adv = self.lab("adv")
-            # pass 0 -> pass 1 of the same unit unless the pair is a single tile (nq odd, middle)
-            e(I("s_cmp_lg_u32", S_PASS, 0), I("s_cbranch_scc1", Label(l_adv)),
-              I("s_sub_u32", S_T[0], S_NQ, 1), I("s_sub_u32", S_T[0], S_T[0], S_UNIT), I("s_cmp_eq_u32", S_T[0], S_UNIT),
-              I("s_cbranch_scc1", Label(l_adv)),
-              I("s_mov_b32", S_PASS, 1), I("s_branch", Label(l_next)),
-              label(l_adv), I("s_mov_b32", S_PASS, 0), I("s_add_u32", S_JOB, S_JOB, S_NWG))
-        else:
-            e(I("s_add_u32", S_JOB, S_JOB, S_NWG))
-        e(I("s_cmp_ge_u32", S_JOB, S_TOTAL), I("s_cbranch_scc1", Label(l_end)))
-        e(label(l_next))
-        # the epilogue's LDS slice and the K/V buffers are disjoint, but the next job's DMA must not overtake the slowest
-        # wave's last K/V reads: all waves passed the last mid-step barrier after their final reads -> safe
-        e(waitcnt(vmcnt=0), I("s_barrier"))
+        e(self.stamp(5))
+        e(I("s_cmp_lg_u32", S_FINAL, 0), I("s_cbranch_scc1", Label(l_end)))
+        self.k_promote()
+        e(self.stamp(0), self.stamp_acc(3))
         e(I("s_branch", Label(l_job)))
-        e(label(l_end), I("s_endpgm"))
+        e(label(l_end), waitcnt(vmcnt=0), self.stamp(7, real=True), self.stamp(9), I("s_endpgm"))
         for blk in self.ool:
             e(blk)
         return self.prog
 
-    # ------------------------------------------------------------------ causal diagonal (tiles NT-4 .. NT-1)
-    def cinit_for(self, _):
-        return None
-
-    def k_causal_diag(self):
-        raise NotImplementedError
-
     # ------------------------------------------------------------------ text
     def text(self):
-        lines = [f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', ".amdhsa_code_object_version 6", ".text",
-                 f".protected {self.name}", f".globl {self.name}", ".p2align 8", f".type {self.name},@function", f"{self.name}:"]
+        lines = [f".protected {self.name}", f".globl {self.name}", ".p2align 8", f".type {self.name},@function", f"{self.name}:"]
         lines += [x.text() for x in self.prog]
         lines += [f".L{self.name}_fend:", f".size {self.name}, .L{self.name}_fend-{self.name}", "",
                   '.section .rodata,"a",@progbits', ".p2align 6, 0x0", f".amdhsa_kernel {self.name}",
@@ -692,8 +826,14 @@ class Gen:
             f"    .wavefront_size: 64"])
 
 
+ABLATIONS = {"kreadv": ("kread_vgpr",), "novmwait": ("novmwait",), "nobarrier": ("nobarrier",), "nomax": ("nomax",), "nofma": ("nofma",),
+             "nodma": ("nodma",), "nokread": ("nokread",), "nostart": ("nostart",), "nofinish": ("nofinish",),
+             "novread": ("novread",), "mfmaonly": ("nodma", "nokread", "nostart", "nofinish", "novread")}
+
+
 def module_text(gens):
-    body = "\n".join(g.text() for g in gens)
+    head = ['.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', ".amdhsa_code_object_version 6", ".text", ""]
+    body = "\n".join(head) + "\n".join(g.text() for g in gens)
     md = ["", ".amdgpu_metadata", "---", "amdhsa.kernels:"] + [g.metadata() for g in gens] + [
         "amdhsa.target: amdgcn-amd-amdhsa--gfx950", "amdhsa.version:", "  - 1", "  - 2", "...", ".end_amdgpu_metadata", ""]
     return body + "\n".join(md)
@@ -702,17 +842,23 @@ def module_text(gens):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("-o", "--output", required=True)
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build: job-timeline stamps into the debug buffer")
     args = ap.parse_args(argv)
     from .check import check
     gens = []
     for dtype in ("bf16", "f16"):
-        for causal in (False,):
-            g = Gen(dtype, causal)
+        for causal in (False, True):
+            g = Gen(dtype, causal, stamps=args.stamps)
             g.build()
             errs = check(g.prog)
             if errs:
                 print(f"{g.name}: {len(errs)} wait-state violations", file=sys.stderr)
                 return 1
+            gens.append(g)
+    if args.stamps:  # timing-only ablations ride in the diagnostic code object
+        for nm, abl in ABLATIONS.items():
+            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=abl)
+            g.build()
             gens.append(g)
     with open(args.output, "w") as f:
         f.write(module_text(gens))

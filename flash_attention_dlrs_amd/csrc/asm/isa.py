@@ -111,9 +111,9 @@ def fmt_operand(o) -> str:
 MFMA_OPS = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16"}
 TRANS_OPS = {"v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"}
 DS_OPS = {"ds_read_b128", "ds_read_b64_tr_b16", "ds_write_b64", "ds_read_b64", "ds_write_b128", "ds_read_b32", "ds_write_b32"}
-VMEM_OPS = {"buffer_load_dwordx4", "buffer_store_dwordx4", "buffer_store_short", "buffer_store_dword", "global_store_dword",
+VMEM_OPS = {"global_store_dwordx2", "buffer_load_dwordx4", "buffer_store_dwordx4", "buffer_store_short", "buffer_store_dword", "global_store_dword",
             "global_store_dwordx4", "buffer_load_dword"}
-SMEM_OPS = {"s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16", "s_memtime"}
+SMEM_OPS = {"s_memrealtime", "s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16", "s_memtime"}
 
 
 @dataclass
@@ -189,7 +189,7 @@ class Inst:
             return d, VCC.regs()
         if op.startswith("s_cmp_"):
             return [("scc", 0)], R(o[0]) + R(o[1])
-        if op.startswith("s_load_") or op == "s_memtime":
+        if op.startswith("s_load_") or op in ("s_memtime", "s_memrealtime"):
             return R(o[0]), (R(o[1]) if len(o) > 1 else [])
         if self.is_mfma:
             return R(o[0]), R(o[1]) + R(o[2]) + R(o[3])

@@ -4,7 +4,10 @@
     .global fa2_a64_hsaco_end
     .balign 4096
 fa2_a64_hsaco_start:
-    .incbin "fa2_a64.hsaco"
+#ifndef FA2_A64_HSACO
+#define FA2_A64_HSACO "fa2_a64.hsaco"
+#endif
+    .incbin FA2_A64_HSACO
 fa2_a64_hsaco_end:
     .byte 0
     .section .note.GNU-stack,"",@progbits
