@@ -19,7 +19,7 @@ from bench import CONFIGS, TORCH_DTYPE, flops  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3_noncausal"
 c = CONFIGS[cfg]
 dev = torch.device("cuda:0")
-NSLOT = 16
+NSLOT = 24
 nwg = 256
 dbg = torch.zeros(nwg * 4 * NSLOT, dtype=torch.int64, device=dev)
 os.environ["FA2_A64_DBG"] = hex(dbg.data_ptr())
@@ -61,6 +61,8 @@ lo = dbg.cpu().view(nwg, 4, NSLOT) & 0xFFFFFFFF
 steps = tiles - 4
 for k, nm in ((10, "phaseA"), (11, "sync"), (12, "phaseB")):
     out[nm + "_cyc_per_step"] = [round(float(lo[:, w, k].double().median()) / steps, 1) for w in range(4)]
+out["seam_steps_cyc"] = [float((d[..., 17] - d[..., 16]).median()), float((d[..., 18] - d[..., 17]).median()),
+                         float((d[..., 19] - d[..., 18]).median()), float((d[..., 4] - d[..., 19]).median()), float((d[..., 16] - d[..., 3]).median())]
 real = (d[..., 7] - d[..., 6]).median().item()  # 100 MHz ticks
 out["clock_ghz"] = round(float(seg["kernel"].median()) / real / 10.0, 3) if real > 0 else None
 out["job_cyc"] = float((d[..., 5] - d[..., 0]).median())

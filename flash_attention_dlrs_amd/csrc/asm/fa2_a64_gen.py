@@ -46,7 +46,7 @@ V_RS = ((200, 201), (202, 203))  # row-sum accumulators [qb][2]
 V_MX = ((204, 205), (206, 207))  # row-max chains [qb][kb]
 V_CO = (208, 209)         # rescale coefficient per query block
 V_T = tuple(range(210, 220))     # temporaries (V_T[2] = v212 is 4-aligned: a zero MFMA operand in the epilogue)
-V_QOFF = 220              # Q load lane offset (row stride qs_n)
+V_QOFF = 220              # (unused)
 V_LANE = 221
 V_EW = 222                # epilogue LDS write base (row i, +8h)
 V_ESW = 223               # epilogue swizzle term swz(i)
@@ -57,6 +57,8 @@ V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), acc
 V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
 V_LSV = (234, 235)        # row sums of the finished job, saved for its epilogue
 V_MSV = (236, 237)        # running maximum of the finished job
+V_DQE, V_DQO = 240, 241   # LDS-DMA per-lane source offsets of the Q rows (row stride qs_n; even / odd 8-row group)
+V_QRE, V_QRO = 242, 243   # Q row-read lane bases in the wave's slice (even / odd k-step)
 V_IMH = 238               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
 V_NINF = 239              # causal: -inf
 
@@ -104,22 +106,23 @@ S_T = tuple(S(88 + k) for k in range(8))  # temporaries s88..s95 (S_T[0] even: u
 S_QROW = (S(96), S(97))          # first row of the wave's query block qb (current job)
 S_DBG = S(98, 2)
 S_KW, S_VW = S(100), S(101)      # 8 * wave * row stride: the wave's row base inside a tile
-S_X0, S_X1 = S(73), S(75)        # spare
+S_LG, S_X1 = S(73), S(75)        # decode shifts: lgH | lgG << 8 | lg(G * nunit) << 16 | pow2-mode << 24;  spare
 S_X2 = S(82)
 
 # LDS map (bytes)
-KB = (0, 16384, 32768, 49152)
-VBASE = 65536
-VB = (0, 16384, 32768, 49152)    # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
-EPI = 131072                     # + 8192 * wave: the wave's 32 x 256-byte output slice (one query block at a time)
-LDS_TOTAL = 163840
+KB = (0, 16384)
+VBASE = 32768
+VB = (0, 16384)                  # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
+EPI = 65536                      # + 16384 * wave: the wave's private 64 x 256-byte slice: the next job's Q rows land here by
+                                 # LDS-DMA (K-tile image) on their way to a[128:191]; later the job's O rows leave through it
+LDS_TOTAL = 131072
 
-KARG_SIZE = 184
-NSLOT = 16
+KARG_SIZE = 192
+NSLOT = 24
 
 
 class Gen:
-    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=()):
+    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2)):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
@@ -131,6 +134,9 @@ class Gen:
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
         self.abl = set(abl)    # timing-only ablations of the steady loop (diagnostic builds; results wrong by construction)
+        self.R, self.dk, self.dv = ring   # ring depth; K(t + dk) and V(t + dv) are streamed in phase B(t): dk <= R + 1, dv <= R
+        assert 3 <= self.dk <= min(self.R + 1, 4) and 2 <= self.dv <= self.R and 4 % self.R == 0
+        self.vm = 8 * min(self.dk - 3, self.dv - 2)  # DMA pieces that may stay in flight across the mid-step barrier
         self.stamps = stamps   # diagnostic build: s_memtime stamps of the job timeline go to the debug buffer
 
     # ------------------------------------------------------------------ small helpers
@@ -211,7 +217,7 @@ class Gen:
           I("s_load_dwordx8", S(4, 8), S_KARG, 0), I("s_load_dwordx4", S(12, 4), S_KARG, 32),
           I("s_load_dwordx16", S(16, 16), S_KARG, 48), I("s_load_dwordx4", S(32, 4), S_KARG, 112),
           I("s_load_dwordx8", S(36, 8), S_KARG, 128), I("s_load_dwordx4", S(44, 4), S_KARG, 160),
-          I("s_load_dwordx2", S_DBG, S_KARG, 176))
+          I("s_load_dwordx2", S_DBG, S_KARG, 176), I("s_load_dword", S_LG, S_KARG, 184))
         lane, t0, t1, t2, t3 = V(V_LANE), V(V_T[0]), V(V_T[1]), V(V_T[2]), V(V_T[3])
         e(I("v_and_b32", lane, 63, V(0)), I("v_lshrrev_b32", t0, 6, V(0)), I("s_nop", 1), I("v_readfirstlane_b32", S_WAVE, t0), I("s_nop", 4),
           I("s_lshl_b32", S_LDSW, S_WAVE, 11))
@@ -256,12 +262,19 @@ class Gen:
         e(waitcnt(lgkmcnt=0, comment="kernel arguments are in"))
         e(I("v_mul_lo_u32", t2, t1, S_KSN), I("v_add_u32", V(V_DKO), t2, t0), I("v_add_u32", V(V_DKO2), 128, V(V_DKO)),
           I("v_mul_lo_u32", t2, t1, S_VSN), I("v_add_u32", V(V_DVO), t2, t0), I("v_add_u32", V(V_DVO2), 128, V(V_DVO)))
-        # ---- Q load lane offset: i * qs_n + 16 h
-        e(comment("Q load / epilogue lane constants"),
+        # ---- Q rows: the same piece shape for the 8-row groups R = 0..7 of the wave's 64 rows; the slot XOR is 2 (R & 1) + (l' >> 4)
+        e(comment("Q staging: LDS-DMA lane offsets (even / odd row group) and row-read bases in the wave's slice"),
+          I("v_and_b32", t0, 3, lane), I("v_bfe_u32", t2, lane, 4, 1),
+          I("v_xor_b32", t3, t0, t2),                       # even R: slot ^ (l' >> 4)
+          I("v_lshrrev_b32", t2, 5, lane), I("v_lshl_or_b32", t3, t2, 2, t3), I("v_lshlrev_b32", t3, 4, t3),
+          I("v_mul_lo_u32", t2, t1, S_QSN), I("v_add_u32", V(V_DQE), t2, t3),
+          I("v_xor_b32", t3, 32, t3),                       # odd R: slot ^ (2 + (l' >> 4)): bit 1 of the slot = bit 5 of 16 * chunk
+          I("v_add_u32", V(V_DQO), t2, t3),
+          I("s_lshl_b32", S_T[0], S_WAVE, 14), I("s_add_u32", S_T[0], S_T[0], EPI),
+          I("v_add_u32", V(V_QRE), S_T[0], V(V_KRE)), I("v_add_u32", V(V_QRO), S_T[0], V(V_KRO)))
+        # ---- epilogue: write base EPI + 16384 wave + 256 i + 8 h; swizzle term ((i & 3) << 2) | ((i >> 2) & 3)
+        e(comment("epilogue lane constants"),
           I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane),
-          I("v_mul_lo_u32", t1, t0, S_QSN), I("v_lshl_add_u32", V(V_QOFF), t3, 4, t1))
-        # ---- epilogue: write base EPI + 8192 wave + 256 i + 8 h; swizzle term ((i & 3) << 2) | ((i >> 2) & 3)
-        e(I("s_lshl_b32", S_T[0], S_WAVE, 13), I("s_add_u32", S_T[0], S_T[0], EPI),
           I("v_lshlrev_b32", t1, 8, t0), I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1),
           I("v_and_b32", t1, 3, t0), I("v_lshlrev_b32", t1, 2, t1), I("v_bfe_u32", t2, t0, 2, 2), I("v_or_b32", t1, t1, t2),
           I("v_mov_b32", V(V_ESW), t1))
@@ -294,7 +307,24 @@ class Gen:
         l_else, l_done = self.lab("dec_else"), self.lab("dec_done")
         t = S_T
         bh = S_X2
+        l_gen = self.lab("dec_generic")
         e(comment("job index -> (b, h), work unit, query block, tile count of the NEXT job"),
+          I("s_lshr_b32", t[0], S_LG, 24), I("s_cmp_eq_u32", t[0], 0), I("s_cbranch_scc1", Label(l_gen)))
+        # H, G, G * nunit powers of two and B * H a multiple of 8 (the host says so): shifts and masks only
+        e(I("s_lshr_b32", t[0], S_JOB, 3),                                   # slot
+          I("s_lshr_b32", t[1], S_LG, 16), I("s_and_b32", t[1], t[1], 255),   # lg(G nunit)
+          I("s_lshr_b32", t[2], t[0], t[1]),                                  # batch
+          I("s_lshl_b32", t[3], 1, t[1]), I("s_sub_u32", t[3], t[3], 1), I("s_and_b32", t[3], t[0], t[3]),   # r
+          I("s_lshr_b32", t[1], S_LG, 8), I("s_and_b32", t[1], t[1], 255),    # lg G
+          I("s_lshr_b32", S_UNIT, t[3], t[1]),                                # unit = r >> lgG
+          I("s_lshl_b32", t[4], 1, t[1]), I("s_sub_u32", t[4], t[4], 1), I("s_and_b32", t[4], t[3], t[4]),   # r % G
+          I("s_lshl_b32", t[2], t[2], t[1]), I("s_add_u32", t[2], t[2], t[4]), I("s_lshl_b32", t[2], t[2], 3),
+          I("s_and_b32", t[0], S_JOB, 7), I("s_add_u32", bh, t[2], t[0]),
+          I("s_and_b32", t[1], S_LG, 255),                                    # lg H
+          I("s_lshr_b32", S_NB, bh, t[1]),
+          I("s_lshl_b32", t[4], 1, t[1]), I("s_sub_u32", t[4], t[4], 1), I("s_and_b32", S_NHH, bh, t[4]))
+        l_qi = self.lab("dec_qi")
+        e(I("s_branch", Label(l_qi)), label(l_gen),
           I("s_and_b32", t[0], S_NBH, 7), I("s_cmp_lg_u32", t[0], 0), I("s_cbranch_scc1", Label(l_else)))
         # slot = id >> 3; GN = G * nunit; batch = slot / GN; r = slot % GN; bh = (batch * G + r % G) * 8 + (id & 7); unit = r / G
         e(I("s_lshr_b32", t[0], S_JOB, 3), I("s_mul_i32", t[1], S_G, S_NUNIT))
@@ -306,6 +336,7 @@ class Gen:
         self.udiv(bh, S_UNIT, S_JOB, S_NUNIT)
         e(label(l_done))
         self.udiv(S_NB, S_NHH, bh, S_H)
+        e(label(l_qi))
         if self.causal:
             # unit u, pass 0: qi = nq - 1 - u (heavy), pass 1: qi = u;  tiles = 4 (qi + 1)
             l_p1, l_pd = self.lab("pass1"), self.lab("passd")
@@ -371,16 +402,36 @@ class Gen:
         out.append(I("s_add_u32", S_KDMA, S_KDMA, S_K64) if which == "k" else I("s_add_u32", S_VDMA, S_VDMA, S_V64))
         return out
 
-    def q_loads(self, b: Reg, hh: Reg, qi: Reg):
-        """Q rows of job (b, hh, qi) of this wave into a[128:191] (16 loads)"""
-        out = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh)
-        out += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_T[0], S_T[0], S_T[1])]
+    def q_stage(self, b: Reg, hh: Reg, qi: Reg):
+        """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the K-tile image (16 pieces of 8 rows x
+        128 bytes: coalesced, ~25 cycles of issue each; the same rows fetched straight into the MFMA operand layout -- 32 rows x
+        32 bytes per instruction -- cost ~210 cycles per load).  Returns (descriptor / offset setup, [pieces])"""
+        setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh)
+        setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
+                  I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
+                  I("s_lshl_b32", S_T[3], S_QSN, 3),                    # 8 rows
+                  I("s_lshl_b32", S_T[4], S_WAVE, 14), I("s_add_u32", S_T[4], S_T[4], EPI)]
+        pieces = []
+        for R in range(8):
+            for half in range(2):
+                pc = []
+                so = S_T[2]
+                if half:
+                    so = S_T[5]
+                    pc.append(I("s_add_u32", so, S_T[2], 128))
+                pc += [I("s_add_u32", M0, S_T[4], 2048 * R + 1024 * half), I("s_nop", 0),
+                       I("buffer_load_dwordx4", V(V_DQO if R & 1 else V_DQE), S_SQ, so, offen=1, lds=1, tag=f"qdma R{R} h{half}")]
+                if half and R < 7:
+                    pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
+                pieces.append(pc)
+        return setup, pieces
+
+    def q_reads(self):
+        """the staged Q rows -> a[128:191] (fragment (qb, ks) = rows 32 qb + i, 16-byte chunk 2 ks + h, as a K row read)"""
+        out = []
         for qb in range(2):
-            out += [I("s_mul_i32", S_T[1], S_T[0], S_QSN)]
             for ks in range(8):
-                out.append(I("buffer_load_dwordx4", A_Q(qb, ks), V(V_QOFF), S_SQ, S_T[1], offen=1, offset=32 * ks, tag="qload"))
-            if qb == 0:
-                out += [I("s_add_u32", S_T[0], S_T[0], 32)]
+                out.append(I("ds_read_b128", A_Q(qb, ks), V(V_QRO if ks & 1 else V_QRE), offset=8192 * qb + 512 * (ks >> 1), tag=f"qread qb{qb} ks{ks}"))
         return out
 
     # ------------------------------------------------------------------ the two phases
@@ -468,7 +519,7 @@ class Gen:
         fill = []
         abl = self.abl if steady else set()
         if with_finish:
-            vr = self.v_reads(t4)
+            vr = self.v_reads(t4 % self.R)
             for k, ins in enumerate(vr):           # 2 reads per gap over the first 16 gaps
                 if "novread" not in abl:
                     fill.append((k * 0.5, [ins]))
@@ -541,7 +592,7 @@ class Gen:
         return out
 
     def phase_b(self, t4, with_pv=True, with_start=True, init=False, with_kread=True, with_dma=True, steady=False,
-                save=False, pre=(), qload=None, mask=None):
+                save=False, pre=(), qload=None, mask=None, early=(), late=()):
         """B(t), t4 = t & 3: P.V(t) from S[p]  ||  start-softmax(t+1) on S[1-p]  ||  K(t+2) reads from KB[(t+2) & 3]
         ||  LDS-DMA V(t+3) -> VB[(t+3) & 3], K(t+4) -> KB[t4].
         init: the tile started here is the first of a job (m := its row maximum, sums := 0, no decision)
@@ -565,15 +616,23 @@ class Gen:
             head += qload
         if mask is not None:
             head += self.mask_block(Y, *mask)
+        # scalar work and register loads that only have to precede this phase's DMA pieces: spread over the first gaps
+        ne = len(early)
+        for k, ins in enumerate(early):
+            fill.append((0.3 + 11.0 * k / max(ne, 1), [ins]))
         if with_kread:
-            for k, ins in enumerate(self.k_reads((t4 + 2) & 3)):
+            for k, ins in enumerate(self.k_reads((t4 + 2) % self.R)):
                 fill.append((0.2 + k * 0.75, [ins]))
         if with_dma:
-            pieces = [self.dma_piece("v", j, (t4 + 3) & 3) for j in range(4)] + [self.dma_piece("k", j, t4) for j in range(4)]
+            pieces = [self.dma_piece("v", j, (t4 + self.dv) % self.R) for j in range(4)] + \
+                [self.dma_piece("k", j, (t4 + self.dk) % self.R) for j in range(4)]
             for k, pc in enumerate(pieces):
                 if "nodma" in abl:
                     continue
-                fill.append((12.5 + 2.3 * k, pc))
+                fill.append((12.5 + 2.3 * k, pc) if not late else (6.0 + 1.2 * k, pc))
+            # further DMA pieces (the next job's Q rows) behind this step's own: the counted waits rely on that order
+            for k, pc in enumerate(late):
+                fill.append((16.0 + 15.5 * k / len(late), pc))
             post += [I("s_add_u32", S_VDMA, S_VDMA, S_V64), I("s_add_u32", S_KDMA, S_KDMA, S_K64)]
         if with_start:
             t0, t1 = V(V_T[0]), V(V_T[1])
@@ -653,12 +712,14 @@ class Gen:
             self.ool.append(blk)
         return body
 
-    def sync_mid(self, steady=False):
+    def sync_mid(self, steady=False, vm=None):
+        if vm is not None:
+            return [waitcnt(vmcnt=vm, lgkmcnt=0), I("s_barrier")]
         if steady and "novmwait" in self.abl:
             return [waitcnt(lgkmcnt=0), I("s_barrier")]
         if steady and "nobarrier" in self.abl:
-            return [waitcnt(vmcnt=8, lgkmcnt=0)]
-        return [waitcnt(vmcnt=8, lgkmcnt=0, comment="the DMA pieces of two steps ago have landed; V fragments in"), I("s_barrier")]
+            return [waitcnt(vmcnt=self.vm, lgkmcnt=0)]
+        return [waitcnt(vmcnt=self.vm, lgkmcnt=0, comment="the DMA pieces of two steps ago have landed; V fragments in"), I("s_barrier")]
 
     def step(self, t4, a_pre=(), **kw):
         """one tile step, t4 = t & 3"""
@@ -668,11 +729,11 @@ class Gen:
         out += [waitcnt(lgkmcnt=0, comment="K fragments in")]
         out += self.phase_a(t4, **{k: v for k, v in kw.items() if k in ("with_qk", "with_finish", "cinit", "steady")})
         out += self.stamp_acc(0)
-        out += self.sync_mid(kw.get("steady", False))
+        out += self.sync_mid(kw.get("steady", False), kw.get("vm"))
         out += self.stamp_acc(1)
         out += [comment(f"---- step {t4}: phase B")]
         out += self.phase_b(t4, **{k: v for k, v in kw.items()
-                                  if k in ("with_pv", "with_start", "init", "with_kread", "with_dma", "steady", "save", "pre", "qload", "mask")})
+                                  if k in ("with_pv", "with_start", "init", "with_kread", "with_dma", "steady", "save", "pre", "qload", "mask", "early", "late")})
         return out
 
     # ------------------------------------------------------------------ epilogue of the current job
@@ -707,22 +768,46 @@ class Gen:
         e(I("s_mov_b64", EXEC, -1))
         e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH))
         # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row i, chunk 4 db + g4, +8 h); one query block at a time.
-        # (S[0] already holds the next job's first scores and v[128:191] its K(1): the row registers are score buffer 1,
-        # whose P was consumed by the job's last P.V)
-        tmp = [V(V_T[6]), V(V_T[7]), V(V_T[8]), V(V_T[9])]
-        addr = V(V_MX[0][0])
-        addr2 = V(V_MX[0][1])
-        rows = [V(SBUF[1] + 4 * k, 4) for k in range(16)]
+        # (S[0] already holds the next job's first scores and v[128:191] its K(1): rows and temporaries are score buffer 1,
+        # whose P was consumed by the job's last P.V.)  A batch = the four 8-byte groups of one 32-column block; the stages
+        # of consecutive batches (accumulator reads | scale | pack, address | LDS write) are woven so that no instruction
+        # waits on its predecessor.
+        rows = [V(SBUF[1] + 4 * k, 4) for k in range(8)]
+        tset = [[V(SBUF[1] + 32 + 16 * sidx + k) for k in range(16)] for sidx in range(2)]
+        aset = [[V(V_T[6]), V(V_T[7]), V(V_T[8]), V(V_T[9])], [V(V_MX[0][0]), V(V_MX[0][1]), V(V_MX[1][0]), V(V_MX[1][1])]]
+        addr2 = V(V_CO[0])
+
+        def weave(*lists):
+            out, idx = [], [0] * len(lists)
+            while any(idx[k] < len(lists[k]) for k in range(len(lists))):
+                for k in range(len(lists)):
+                    if idx[k] < len(lists[k]):
+                        out.append(lists[k][idx[k]])
+                        idx[k] += 1
+            return out
         for qb in range(2):
+            stages = []  # per batch: [reads, muls + address, packs, writes]
             for db in range(4):
+                tm, ad = tset[db & 1], aset[db & 1]
+                src = A_O(qb, db)
+                rd = [I("v_accvgpr_read_b32", tm[k], src.sub(k)) for k in range(16)]
+                mu = [I("v_mul_f32", tm[k], tm[k], inv[qb]) for k in range(16)]
+                ax = [I("v_xor_b32", ad[g4], 4 * db + g4, V(V_ESW)) for g4 in range(4)]
+                al = [I("v_lshl_add_u32", ad[g4], ad[g4], 4, V(V_EW)) for g4 in range(4)]
+                cv = []
                 for g4 in range(4):
-                    src = A_O(qb, db)
-                    e([I("v_accvgpr_read_b32", tmp[k], src.sub(4 * g4 + k)) for k in range(4)])
-                    e(I("v_xor_b32", addr, 4 * db + g4, V(V_ESW)))
-                    e([I("v_mul_f32", tmp[k], tmp[k], inv[qb]) for k in range(4)])
-                    e(I("v_lshl_add_u32", addr, addr, 4, V(V_EW)))
-                    e(I(self.cvt, tmp[0], tmp[0], tmp[1]), I(self.cvt, tmp[1], tmp[2], tmp[3]))
-                    e(I("ds_write_b64", addr, V(tmp[0].idx, 2)))
+                    cv += [I(self.cvt, tm[4 * g4], tm[4 * g4], tm[4 * g4 + 1]), I(self.cvt, tm[4 * g4 + 1], tm[4 * g4 + 2], tm[4 * g4 + 3])]
+                wr = [I("ds_write_b64", ad[g4], V(tm[4 * g4].idx, 2)) for g4 in range(4)]
+                stages.append((rd, weave(mu, ax), weave(cv, al), wr))
+            # software pipeline over the four batches (two register sets): batch b + 1 is read while batch b is scaled, ...
+            e(stages[0][0])
+            e(weave(stages[0][1], stages[1][0]))
+            e(stages[0][2], stages[0][3])
+            e(weave(stages[1][1], stages[2][0]))
+            e(stages[1][2], stages[1][3])
+            e(weave(stages[2][1], stages[3][0]))
+            e(stages[2][2], stages[2][3])
+            e(stages[3][1], stages[3][2], stages[3][3])
             # read back whole rows: row 4 k + a
             for k in range(8):
                 if k & 3:
@@ -730,11 +815,11 @@ class Gen:
                     src_a = addr2
                 else:
                     src_a = V(V_ER)
-                e(I("ds_read_b128", rows[8 * qb + k], src_a, offset=1024 * k))
+                e(I("ds_read_b128", rows[k], src_a, offset=1024 * k))
             e(I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2))
             for k in range(8):
                 e(waitcnt(lgkmcnt=7 - k))
-                e(I("buffer_store_dwordx4", rows[8 * qb + k], V(V_EO), S_SQ, S_T[0], offen=1))
+                e(I("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0], offen=1))
                 if k < 7:
                     e(I("s_add_u32", S_T[0], S_T[0], S_T[1]))
         # O^T := 0 for the next job, on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
@@ -758,12 +843,16 @@ class Gen:
         e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH))
         e(I("s_mov_b32", S_KDMA, S_KW), I("s_mov_b32", S_VDMA, S_VW))
         e(self.stamp(0))
-        e(self.dma_tile("k", 0), self.dma_tile("v", 0), self.dma_tile("k", 1), self.dma_tile("v", 1), self.dma_tile("k", 2))
-        e(self.q_loads(S_B, S_HH, S_QI))
+        for j in range(self.dk - 1):
+            e(self.dma_tile("k", j % self.R))
+            if j < self.dv - 1:
+                e(self.dma_tile("v", j % self.R))
+        qs_setup, qs_pieces = self.q_stage(S_B, S_HH, S_QI)
+        e(qs_setup, qs_pieces)
         e([I("v_accvgpr_write_b32", A(k), 0) for k in range(128)])   # O^T := 0
         e(waitcnt(vmcnt=0), I("s_barrier"))
         e(self.stamp(1))
-        e(self.k_reads(0))
+        e(self.q_reads(), self.k_reads(0))
         # step -1 (buffers as t4 = 3): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(2), K(3)
         e(self.step(3, with_qk=True, with_finish=False, with_pv=False, init=True, mask=(0, (S_NT, 4)) if self.causal else None))
         e(self.stamp(2), self.stamp_flush(), self.stamp_acc(3))
@@ -784,12 +873,29 @@ class Gen:
         if True:
             kpre = self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_NB, S_NHH) + [I("s_mov_b32", S_KDMA, S_KW)] + \
                 self.make_desc(S_NVRS, S_V, S_VSB, S_VSH, S_NB, S_NHH)
-            e(self.step(0, pre=kpre, mask=(1,) if cm else None))        # K(t+4) = next job's K(0)
             vpre = [I("s_mov_b32", S_VRS.sub(k), S_NVRS.sub(k)) for k in range(4)] + [I("s_mov_b32", S_VDMA, S_VW)]
-            e(self.step(1, pre=vpre, mask=(2,) if cm else None))        # V(t+3) = next job's V(0)
-            e(self.step(2, qload=self.q_loads(S_NB, S_NHH, S_NQI), mask=(3,) if cm else None))   # Q rows of the next job (Q was last read in this step's A)
-            e(self.step(3, a_pre=[waitcnt(vmcnt=8, comment="Q rows of the next job are in")], init=True, save=True,
-                        mask=(0, (S_NNT, 4)) if cm else None))           # the next job's tile 0 is diagonal if it has only four
+            sk, sv = 4 - self.dk, 4 - self.dv      # seam step whose phase B streams the next job's first K / V tile
+            qs_setup, qs_pieces = self.q_stage(S_NB, S_NHH, S_NQI)
+            for st in range(4):
+                kw = dict(mask=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None)
+                early, pre = [], []
+                if st == 0:
+                    # the next job's Q rows start their way into the wave's LDS slice, BEHIND this step's K / V pieces; the
+                    # next barrier wait leaves them in flight (vmcnt(16 + ...)), the one after retires them
+                    early += qs_setup
+                    kw.update(late=qs_pieces)
+                if st == 1:
+                    kw.update(vm=self.vm + 16)
+                if st == sk:
+                    early += kpre
+                if st == sv:
+                    pre += vpre
+                if st == 2:
+                    early += self.q_reads()      # slice -> a[128:191] (Q was last read by this step's phase A)
+                if st == 3:
+                    kw.update(init=True, save=True)
+                e(self.stamp(16 + st))
+                e(self.step(st, early=early, pre=pre, **kw))
         e(self.stamp(4))
         self.k_epilogue()
         e(self.stamp(5))

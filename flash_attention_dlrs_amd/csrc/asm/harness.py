@@ -23,17 +23,22 @@ def from_dt(u16, dtype):
     return u16.view(np.float16).astype(np.float32)
 
 
-def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, nbh, nwg, dbg=0):
+def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, nbh, nwg, dbg=0, pow2=True):
     """ptrs: Q,K,V,O,L addresses; strides_bh: (qs_b, qs_h, ks_b, ks_h, vs_b, vs_h, os_b, os_h, ls_b, ls_h) in bytes;
     strides_n: (qs_n, ks_n, vs_n, os_n) in bytes -- the layout of fa2_a64_gen.k_setup"""
     b = struct.pack("<5Q", *ptrs) + struct.pack("<10q", *strides_bh) + struct.pack("<4i", *strides_n)
     b += struct.pack("<4i", N, H, nq, total) + struct.pack("<2f2i", c, thr, nunit, G) + struct.pack("<2i", nbh, nwg)
     b += struct.pack("<Q", dbg)
+    lg = 0
+    ispow2 = lambda x: x > 0 and (x & (x - 1)) == 0
+    if pow2 and nbh % 8 == 0 and ispow2(H) and ispow2(G) and ispow2(G * nunit):
+        lg = (H.bit_length() - 1) | ((G.bit_length() - 1) << 8) | (((G * nunit).bit_length() - 1) << 16) | (1 << 24)
+    b += struct.pack("<II", lg, 0)
     assert len(b) == KARG_SIZE, len(b)
     return b
 
 
-def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1):
+def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1, pow2=True):
     """Q, K, V: float32 arrays (B, H, N, 128), rounded to dtype here.  Returns O (B,H,N,128) f32, L (B,H,N) f32."""
     B, H, N, D = Q.shape
     assert D == 128 and N % 256 == 0
@@ -52,9 +57,9 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     total = nunit * nbh
     nwg = nwg or min(total, 256)
     sb, sh, sn = H * N * D * 2, N * D * 2, D * 2
-    thr = 24.0 if dtype == "bf16" else 12.0
+    thr = 60.0 if dtype == "bf16" else 12.0
     ka = pack_kargs([bufs[k][0] for k in "QKVOL"], (sb, sh) * 4 + (H * N * 2, N * 2), (sn,) * 4, N, H, nq, total,
-                    float(scale * LOG2E), thr, nunit, G, nbh, nwg)
+                    float(scale * LOG2E), thr, nunit, G, nbh, nwg, pow2=pow2)
     ka_arr = np.frombuffer(ka, np.uint8).copy()
     ka_addr = mem.alloc(ka_arr)
     steps = 0

@@ -17,7 +17,7 @@ extern "C" const unsigned char fa2_a64_hsaco_end[];
 
 namespace {
 
-// kernel-argument block: the layout of Gen.k_setup() in asm/fa2_a64_gen.py (184 bytes)
+// kernel-argument block: the layout of Gen.k_setup() in asm/fa2_a64_gen.py (192 bytes)
 struct __attribute__((packed)) A64Args {
     const void *Q, *K, *V;
     void *O, *L;
@@ -28,8 +28,10 @@ struct __attribute__((packed)) A64Args {
     int32_t nunit, group;
     int32_t nbh, nwg;
     void *dbg;
+    uint32_t lg;   // lgH | lgG << 8 | lg(G * nunit) << 16 | 1 << 24 when those are powers of two and B * H % 8 == 0, else 0
+    uint32_t pad;
 };
-static_assert(sizeof(A64Args) == 184, "kernel-argument layout");
+static_assert(sizeof(A64Args) == 192, "kernel-argument layout");
 
 constexpr int kMaxDev = 64;
 struct DevState {
@@ -136,6 +138,14 @@ int fa2_launch_a64(const Fa2Problem &p) {
     if (slots < 8) slots = 8;
     a.nwg = a.total < slots ? a.total : slots;
     a.dbg = nullptr;
+    {
+        auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
+        auto lg2 = [](int x) { int l = 0; while ((1 << l) < x) ++l; return l; };
+        const int gn = a.group * a.nunit;
+        a.lg = ((a.nbh & 7) == 0 && pow2(p.H) && pow2(a.group) && pow2(gn))
+                   ? (uint32_t)(lg2(p.H) | (lg2(a.group) << 8) | (lg2(gn) << 16) | (1 << 24)) : 0u;
+        a.pad = 0;
+    }
 #ifdef FA2_A64_STAMPS
     // diagnostic library only (make stamps): the kernels carry s_memtime stamps and write them to the buffer whose device
     // address the harness passes in FA2_A64_DBG (benchmarks/a64_stamps.py)

@@ -94,6 +94,11 @@ int pick_variant(const Fa2Problem &p) {
         } else {
             if (wg256 < 160 || !even) return FA2_VARIANT_MFMA16D_W4;
         }
+        // d = 128, N a multiple of 256, enough 256-row jobs to fill the CUs: the generated assembly kernel A64 (4 waves x 64
+        // rows, one wave per SIMD, O / Q / V^T in the accumulator file).  Against MFMA16H on the same MI355X (interleaved
+        // rounds, benchmarks/variants.py, profiles/r02/): c3 causal +11 %, c3 shape non-causal +12 %, N = 2048 causal +16 %,
+        // B16 H64 N2048 +15 %, N = 8192 / 16384 causal +9 %.
+        if (fa2_a64_supports(p)) return FA2_VARIANT_A64;
         // 8-wave tiles: MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop).  Against MFMA16D on
         // MI355X (benchmarks/lottery.py, alternating order): non-causal +4.4 % (d = 128, N = 4096), +3.4 % (N = 8192),
         // +9 % (d = 64); causal, once its causal kernels got a translation unit of their own: +4.1 % at the north-star

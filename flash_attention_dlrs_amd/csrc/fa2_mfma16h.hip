@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16h_kernel(const DmaAr
     // fp32 exponent range (24 leaves 2^24 * N far below fp32 overflow in l and O); f16 P must stay below 65504.
     // On N(0,1) inputs at scale 1 (score sigma ~ 16 log2 units) a threshold of 8 still fired ~20 times per wave
     // and 4096 keys -- each time the whole workgroup waits at the next barrier -- 24 makes it rare.
-    constexpr float kThr = sizeof(T) == 2 && __is_same(T, _Float16) ? 12.0f : 24.0f;
+    constexpr float kThr = sizeof(T) == 2 && __is_same(T, _Float16) ? 12.0f : 60.0f;  // bf16: 60 (round 2): see fa2_a64.hip
 
     auto qk = [&](f32x16 &s, int koff) __attribute__((always_inline)) {  // koff = buffer base + half * 32 rows
 #pragma unroll

@@ -1,0 +1,202 @@
+"""GPU parity tests of the generated assembly kernel (variant "a64": f16 / bf16, d = 128, N a multiple of 256), through the C ABI.
+
+(a) seeded inputs against the CPU oracle (oracle/fa2_oracle.c) at sizes it finishes in seconds: every (dtype, causal, scale),
+    several jobs per workgroup, permuted (B, N, H, d) storage, padded row strides;
+(b) the deferred-rescale path forced by a late jump of one row's maximum; NaN / Inf inputs against the oracle;
+(c) BASELINE.json configs[3] and configs[4] at their full per-GPU shard sizes (c4: B8 H8 N8192 bf16 -- the default table
+    sends it to this kernel; c5: B16 H8 N16384 e4m3 -- the fp8 kernel), through size-independent properties.
+Tolerances as tests/test_fwd_parity.py: bf16 |O - ref| <= 5e-2, f16 6e-3, L one ulp of the dtype.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import flash_attention_dlrs_amd as fa  # noqa: E402
+from flash_attention_dlrs_amd import _lib  # noqa: E402
+
+DEV = torch.device("cuda:0")
+O_TOL = {torch.float16: 6e-3, torch.bfloat16: 5e-2}
+ORACLE_NAME = {torch.float16: "float16", torch.bfloat16: "bfloat16"}
+
+
+def ulp(dtype, x):
+    mant = {torch.float16: 10, torch.bfloat16: 7}[dtype]
+    return 2.0 ** (math.floor(math.log2(max(abs(x), 1e-30))) - mant)
+
+
+def rand3(shape, dtype, seed, spread=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return tuple((torch.randn(*shape, generator=gen) * spread).to(dtype) for _ in range(3))
+
+
+def oracle_fwd(oracle, Q, K, V, dtype, causal, scale=1.0):
+    f = lambda t: t.float().contiguous().numpy()
+    O, L = oracle.forward(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, scale=scale, B_r=64, B_c=64)
+    return torch.from_numpy(O), torch.from_numpy(L)
+
+
+def a64(Q, K, V, causal=False, scale=1.0, variant="a64"):
+    O, L = fa.flash_attention_forward(Q.to(DEV), K.to(DEV), V.to(DEV), DEV, causal=causal, scale=scale, variant=variant)
+    torch.cuda.synchronize()
+    return O.cpu(), L.cpu()
+
+
+def check(O, L, O_ref, L_ref, dtype):
+    assert torch.isfinite(O.float()).all()
+    assert (O.float() - O_ref).abs().max() <= O_TOL[dtype]
+    assert (L.float().flatten() - L_ref.flatten()).abs().max() <= 1.01 * ulp(dtype, L_ref.abs().max().item())
+
+
+SHAPES = [(1, 1, 256), (2, 3, 512), (1, 2, 768), (1, 5, 1024)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_seeded_vs_oracle(oracle, dtype, causal, shape):
+    B, H, N = shape
+    Q, K, V = rand3((B, H, N, 128), dtype, seed=N + H)
+    check(*a64(Q, K, V, causal), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
+
+
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 128 ** -0.5), (torch.float16, 0.25)])
+def test_scale_and_default_table(oracle, dtype, scale):
+    Q, K, V = rand3((1, 2, 512, 128), dtype, seed=5)
+    O_ref, L_ref = oracle_fwd(oracle, Q, K, V, dtype, True, scale)
+    check(*a64(Q, K, V, True, scale), O_ref, L_ref, dtype)
+
+
+def test_default_table_picks_a64_for_the_north_star_shape():
+    assert _lib.query_tile(4096, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64
+    assert _lib.query_tile(8192, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
+    assert _lib.query_tile(4000, 128, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64   # N not a multiple of 256
+
+
+def test_many_jobs_per_workgroup_and_job_order(oracle):
+    """more jobs than CUs: every workgroup walks several jobs (seam: next-job prefetch, epilogue between jobs), causal pairs"""
+    dtype = torch.bfloat16
+    Q, K, V = rand3((3, 48, 512, 128), dtype, seed=9)      # 288 (b, h) x 2 query blocks = 576 jobs, B * H not a power of two
+    for causal in (False, True):
+        O, L = a64(Q, K, V, causal)
+        # the oracle on a few heads (it takes seconds per head at this size), all heads against each other through SDPA
+        for (b, h) in ((0, 0), (1, 17), (2, 47)):
+            O_ref, L_ref = oracle_fwd(oracle, Q[b:b + 1, h:h + 1], K[b:b + 1, h:h + 1], V[b:b + 1, h:h + 1], dtype, causal)
+            check(O[b:b + 1, h:h + 1], L[b:b + 1, h:h + 1], O_ref, L_ref, dtype)
+        ref = torch.nn.functional.scaled_dot_product_attention(Q.to(DEV).float(), K.to(DEV).float(), V.to(DEV).float(),
+                                                               scale=1.0, is_causal=causal).cpu()
+        assert (O.float() - ref).abs().max() <= O_TOL[dtype]
+
+
+def test_strided_inputs(oracle):
+    """(B, N, H, d) storage viewed as (B, H, N, d) (row stride H * d), and rows padded to 136 elements"""
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(21)
+    Q, K, V = (torch.randn(2, 512, 3, 128, generator=gen).to(dtype).transpose(1, 2) for _ in range(3))
+    assert not Q.is_contiguous()
+    check(*a64(Q, K, V, True), *oracle_fwd(oracle, Q, K, V, dtype, True), dtype)
+    Qp, Kp, Vp = (torch.randn(1, 2, 256, 136, generator=gen).to(dtype)[..., :128] for _ in range(3))
+    assert Qp.stride(2) == 136
+    O, L = fa.flash_attention_forward(Qp.to(DEV), Kp.to(DEV), Vp.to(DEV), DEV, variant="a64")
+    check(O.cpu(), L.cpu(), *oracle_fwd(oracle, Qp, Kp, Vp, dtype, False), dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rescale_branch_is_exercised(oracle, dtype):
+    """the running maximum of one row jumps far beyond the deferral threshold (60 / 12 log2 units) in the last tiles, after O
+    and l are non-zero: O *= coeff, l *= coeff are taken (cdna_hip_programming.md rule 26)"""
+    B, H, N = 1, 2, 1024
+    Q, K, V = rand3((B, H, N, 128), torch.float32, seed=33, spread=0.3)
+    K = K * torch.linspace(0.2, 2.0, N).view(1, 1, N, 1)
+    K[:, :, N - 5] = Q[:, :, 7] * 8.0
+    K[:, :, 300] = Q[:, :, 200] * 6.0
+    Q, K, V = (t.to(dtype) for t in (Q, K, V))
+    for causal in (False, True):
+        check(*a64(Q, K, V, causal), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
+
+
+@pytest.mark.parametrize("variant", ["a64", "mfma16h", "mfma16d_w4"])
+def test_nan_and_inf_inputs_propagate_like_the_oracle(oracle, variant):
+    """A NaN in Q poisons its row, a NaN in V its column of the rows that see it, a NaN key every row that sees it; +Inf in V
+    gives +Inf / NaN as the oracle says.  (The default kernels are built with -fno-honor-nans: this pins the behaviour.)"""
+    dtype = torch.bfloat16
+    Q, K, V = rand3((1, 1, 256, 128), dtype, seed=3, spread=0.5)
+    Q[0, 0, 10, 3] = float("nan")
+    V[0, 0, 50, 7] = float("nan")
+    V[0, 0, 60, 9] = float("inf")
+    O_ref, L_ref = oracle_fwd(oracle, Q, K, V, dtype, False)
+    O, L = a64(Q, K, V, False, variant=variant)
+    nan_ref, nan = torch.isnan(O_ref), torch.isnan(O.float())
+    assert torch.equal(nan, nan_ref), (variant, nan.sum().item(), nan_ref.sum().item())
+    inf_ref = torch.isinf(O_ref)
+    assert torch.equal(torch.isinf(O.float()), inf_ref)
+    ok = ~(nan_ref | inf_ref)
+    assert (O.float()[ok] - O_ref[ok]).abs().max() <= O_TOL[dtype]
+    assert torch.equal(torch.isnan(L.float().flatten()), torch.isnan(L_ref.flatten()))
+    # causal (our extension): the oracle skips masked keys, SDPA multiplies their V by a zero weight (0 * NaN = NaN).  The
+    # kernels skip whole tiles above the diagonal and multiply by zero inside the diagonal tile: between the two.
+    O_ref, _ = oracle_fwd(oracle, Q, K, V, dtype, True)
+    O, _ = a64(Q, K, V, True, variant=variant)
+    sdpa = torch.nn.functional.scaled_dot_product_attention(Q.float(), K.float(), V.float(), scale=1.0, is_causal=True)
+    bad, lo, hi = ~torch.isfinite(O.float()), ~torch.isfinite(O_ref), ~torch.isfinite(sdpa)
+    assert (bad | ~lo).all() and (hi | ~bad).all()            # lo subset of bad subset of hi
+    assert (O.float()[~bad] - O_ref[~bad]).abs().max() <= O_TOL[dtype]
+
+
+def test_unsupported_shapes_raise_and_auto_falls_back():
+    Q, K, V = rand3((1, 2, 300, 128), torch.bfloat16, seed=1)
+    with pytest.raises(TypeError):
+        a64(Q, K, V)
+    O, _ = a64(Q, K, V, variant="auto")
+    ref = torch.nn.functional.scaled_dot_product_attention(Q.float(), K.float(), V.float(), scale=1.0)
+    assert (O.float() - ref).abs().max() <= O_TOL[torch.bfloat16]
+
+
+# ----------------------------------------------------------------------------- full per-GPU shards of BASELINE.json configs[3], [4]
+def test_c4_per_gpu_shard_properties():
+    """configs[3]: B8 H32 N8192 d128 bf16 head-sharded over 4 GPUs -> one GPU's shard B8 H8 N8192, non-causal"""
+    dtype, B, H, N = torch.bfloat16, 8, 8, 8192
+    torch.manual_seed(42)
+    Q, K, V = (torch.randn(B, H, N, 128, device=DEV).to(dtype) for _ in range(3))
+    assert _lib.query_tile(N, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
+    O, L = fa.flash_attention_forward(Q, K, V, DEV)
+    O2, L2 = fa.flash_attention_forward(Q, K, V, DEV)
+    assert torch.equal(O, O2) and torch.equal(L, L2)                                   # run-to-run bit equality
+    parts = [fa.flash_attention_forward(Q[:, h0:h0 + 2].contiguous(), K[:, h0:h0 + 2].contiguous(),
+                                        V[:, h0:h0 + 2].contiguous(), DEV)[0] for h0 in range(0, H, 2)]
+    assert torch.equal(torch.cat(parts, dim=1), O)                                     # bit-identical head indexing
+    O1, _ = fa.flash_attention_forward(Q, K, torch.ones_like(V), DEV)
+    assert (O1.float() - 1).abs().max().item() <= O_TOL[dtype]                         # V = 1 => O = 1
+    for (b, h) in ((0, 0), (7, 7), (3, 5)):                                            # fp32 attention of the bf16 inputs
+        S = Q[b, h].float() @ K[b, h].float().T
+        ref = torch.softmax(S, dim=-1) @ V[b, h].float()
+        assert (O[b, h].float() - ref).abs().max().item() <= O_TOL[dtype]
+        lse2 = torch.logsumexp(S, dim=-1) * math.log2(math.e)
+        assert (L[b, h].float().flatten() - lse2).abs().max().item() <= 1.01 * ulp(dtype, lse2.abs().max().item())
+
+
+def test_c5_full_per_gpu_shard_properties():
+    """configs[4]: B16 H64 N16384 d128 fp8 over 8 GPUs -> one GPU's FULL shard B16 H8 N16384 e4m3 (1 GiB of Q, K, V, O)"""
+    dtype, B, H, N = torch.float8_e4m3fn, 16, 8, 16384
+    torch.manual_seed(42)
+    Q, K, V = ((torch.randn(B, H, N, 128, device=DEV) * 0.5).to(dtype) for _ in range(3))
+    O, L = fa.flash_attention_forward(Q, K, V, DEV)
+    O2, L2 = fa.flash_attention_forward(Q, K, V, DEV)
+    u8 = lambda t: t.view(torch.uint8)
+    assert torch.equal(u8(O), u8(O2)) and torch.equal(u8(L), u8(L2))
+    parts = [fa.flash_attention_forward(Q[b0:b0 + 4].contiguous(), K[b0:b0 + 4].contiguous(), V[b0:b0 + 4].contiguous(), DEV)[0]
+             for b0 in range(0, B, 4)]
+    assert torch.equal(u8(torch.cat(parts, dim=0)), u8(O))                             # batch shards == the full run
+    O1, _ = fa.flash_attention_forward(Q, K, torch.ones(B, H, N, 128, device=DEV).to(dtype), DEV)
+    assert (O1.float() == 1).all()
+    assert torch.isfinite(O.float()).all() and torch.isfinite(L.float()).all()
+    for (b, h) in ((0, 0), (15, 7)):
+        S = Q[b, h].double() @ K[b, h].double().T
+        ref = (torch.softmax(S, dim=-1) @ V[b, h].double()).float()
+        rel = ((O[b, h].float() - ref).abs() / ref.abs().clamp(min=0.05)).flatten()
+        assert rel.median() <= 2.0 ** -4 and rel.kthvalue(int(0.99 * rel.numel())).values <= 3 * 2.0 ** -3
+        lse2 = (torch.logsumexp(S, dim=-1) * math.log2(math.e)).float()
+        assert ((L[b, h].float().flatten() - lse2).abs() <= 2.0 ** -3 * lse2.abs() + 1e-3).all()

@@ -1,0 +1,76 @@
+"""CPU tests of the generated assembly kernel (variant a64) -- no GPU needed.
+
+The generator's instruction stream is (1) checked for wait-state violations, (2) assembled for gfx950, and (3) executed by the
+wave64 emulator (flash_attention_dlrs_amd/csrc/asm/emu.py: test infrastructure, asynchronous loads poisoned until their
+s_waitcnt) for small problems, whose O and L are compared with the CPU oracle (oracle/fa2_oracle.c) in the kernel's I/O
+dtype.  Tolerances: bf16 |O - oracle| <= 5e-2 (the bar of tests/test_fwd_parity.py), f16 6e-3, L one ulp of the dtype.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from flash_attention_dlrs_amd.csrc.asm import harness
+from flash_attention_dlrs_amd.csrc.asm.check import check
+from flash_attention_dlrs_amd.csrc.asm.fa2_a64_gen import KARG_SIZE, Gen, module_text
+
+O_TOL = {"bf16": 5e-2, "f16": 6e-3}
+ORACLE_DT = {"bf16": "bfloat16", "f16": "float16"}
+_PROGS = {}
+
+
+def prog(dtype, causal):
+    if (dtype, causal) not in _PROGS:
+        g = Gen(dtype, causal)
+        _PROGS[(dtype, causal)] = (g, g.build())
+    return _PROGS[(dtype, causal)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_generated_stream_has_no_wait_state_violation(dtype, causal):
+    _, p = prog(dtype, causal)
+    assert check(p, verbose=False) == []
+
+
+def test_generated_module_assembles_for_gfx950(tmp_path):
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm assembler here")
+    gens = [prog(dt, c)[0] for dt in ("bf16", "f16") for c in (False, True)]
+    src = tmp_path / "a64.s"
+    src.write_text(module_text(gens))
+    subprocess.check_call([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src),
+                           "-o", str(tmp_path / "a64.o")])
+    assert KARG_SIZE == 192   # the packed struct A64Args of fa2_a64.hip (static_assert there)
+
+
+def _run(oracle, dtype, causal, B, H, N, scale=1.0, seed=0, spike=False, **kw):
+    rng = np.random.default_rng(seed)
+    Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) for _ in range(3))
+    if spike:   # a late jump of one row's maximum far beyond the deferred-rescale threshold (60 / 12 log2 units)
+        K[:, :, N - 40] = 8.0 * Q[:, :, 5]
+    _, p = prog(dtype, causal)
+    O, L, _ = harness.run(p, Q, K, V, dtype=dtype, causal=causal, scale=scale, **kw)
+    rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
+    O_ref, L_ref = oracle.forward(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=causal, scale=scale, B_r=64, B_c=64)
+    assert not np.isnan(O).any()
+    assert np.abs(O - O_ref).max() <= O_TOL[dtype], np.abs(O - O_ref).max()
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(L_ref).max())) - (7 if dtype == "bf16" else 10))
+    assert np.abs(L - L_ref[..., 0] if L_ref.ndim == 4 else L - L_ref).max() <= 1.01 * ulp
+
+
+@pytest.mark.parametrize("dtype,causal", [("bf16", False), ("bf16", True), ("f16", True)])
+def test_emulated_kernel_matches_oracle_one_job(oracle, dtype, causal):
+    _run(oracle, dtype, causal, 1, 1, 256)
+
+
+def test_emulated_kernel_job_stream_and_wave_order(oracle):
+    # three jobs on one workgroup (seam, next-job prefetch, epilogue between jobs), waves released in a permuted order
+    _run(oracle, "bf16", True, 1, 3, 256, nwg=1, order=[2, 0, 3, 1], seed=1)
+
+
+def test_emulated_kernel_rescale_path(oracle):
+    _run(oracle, "bf16", False, 1, 1, 512, spike=True, seed=2)
