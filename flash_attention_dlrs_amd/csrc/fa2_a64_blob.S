@@ -2,6 +2,8 @@
     .section .rodata
     .global fa2_a64_hsaco_start
     .global fa2_a64_hsaco_end
+    .hidden fa2_a64_hsaco_start
+    .hidden fa2_a64_hsaco_end
     .balign 4096
 fa2_a64_hsaco_start:
 #ifndef FA2_A64_HSACO
