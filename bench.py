@@ -58,9 +58,21 @@ def flops(c):
     return f * 0.5 if c["causal"] else f
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(c, budget_s=12.0):
-    """The reference's CPU path -- torch SDPA(scale=1) on fp32 CPU tensors (src/test_correctness.py:33) --
-    on a bounded sample of the same workload: same N, d, causal; B=1 and a few heads."""
+    """The reference's CPU path -- torch SDPA(scale=1) on fp32 CPU tensors (src/test_correctness.py:33) -- on a bounded
+    sample of the same workload (same N, d, causal; B=1 and a few heads), in both flavours the reference's bench times
+    (src/bench.py:80,83-85): the default backend and the "naive" SDPBackend.MATH one."""
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
     Hs = min(4, c["H"])
@@ -68,19 +80,33 @@ def cpu_baseline(c, budget_s=12.0):
     g = torch.Generator().manual_seed(42)
     Q, K, V = (torch.randn(1, Hs, c["N"], c["d"], generator=g) for _ in range(3))
     fn = lambda: torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1.0, is_causal=c["causal"])
-    fn()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        fn()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 50:
-            break
+
+    def timed(f, budget):
+        f()
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            f()
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget or reps >= 50:
+                return reps, el
+    reps, el = timed(fn, budget_s * 0.5)
     gf = flops(sc) * reps / el / 1e9
-    out = {"value": round(gf / 1e3, 5), "unit": "TFLOP/s", "cores": ncores, "kind": "reference",
-           "sample": f"torch SDPA(scale=1) fp32 on CPU, B=1 H={Hs} N={c['N']} d={c['d']} causal={c['causal']}, "
-                     f"{reps} reps in {el:.1f}s", "gflops": round(gf, 2)}
+    out = {"value": round(gf / 1e3, 5), "unit": "TFLOP/s", "cores": ncores, "cpu": cpu_model(), "kind": "reference",
+           "sample": f"torch SDPA(scale=1) fp32 on CPU, default backend, B=1 H={Hs} N={c['N']} d={c['d']} "
+                     f"causal={c['causal']}, {reps} reps in {el:.1f}s", "gflops": round(gf, 2)}
+    try:  # the "naive" flavour: SDPBackend.MATH materialises the N x N scores (src/bench.py:83-85)
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+
+        def fn_math():
+            with sdpa_kernel(SDPBackend.MATH):
+                return fn()
+        reps_m, el_m = timed(fn_math, budget_s * 0.4)
+        out["math_backend"] = {"value": round(flops(sc) * reps_m / el_m / 1e12, 5), "unit": "TFLOP/s",
+                               "sample": f"same sample under SDPBackend.MATH, {reps_m} reps in {el_m:.1f}s"}
+    except Exception as e:
+        out["math_backend"] = {"error": str(e)[:100]}
     # the oracle's scalar C port, one core, on a smaller slice (N^2 work: keep it to a few seconds)
     try:
         from oracle import fa2_oracle
@@ -119,14 +145,67 @@ def measured_peak(dtype):
     (scripts/probes/mfma_peak.hip -> profiles/rNN/roofline.json) -- context for `frac`, which stays against the vendor
     peak.  None if no probe result is committed."""
     import glob
-    key = {"bf16": "bf16_random", "fp16": "bf16_random", "fp8": "fp8_random", "f32": "f32_random"}.get(dtype)
+    keys = {"bf16": ("bf16_random",), "fp16": ("f16_random", "bf16_random"), "fp8": ("fp8_random",), "f32": ("f32_random",)}.get(dtype, ())
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "roofline.json")), reverse=True):
         try:
             with open(f) as fh:
-                return {"tflops": json.load(fh)["mfma_only_tflops"][key], "source": os.path.relpath(f, ROOT)}
+                d = json.load(fh)["mfma_only_tflops"]
+            for key in keys:
+                if key in d:
+                    return {"tflops": d[key], "source": os.path.relpath(f, ROOT), "key": key}
         except Exception:
             continue
     return None
+
+
+# BASELINE.json configs[3] / configs[4]: the whole problem, sharded over the heads (c4) or over batch x heads (c5)
+STRONG = {4: dict(name="c4", B=8, H=32, N=8192, d=128, dtype="bf16", causal=False),
+          8: dict(name="c5", B=16, H=64, N=16384, d=128, dtype="fp8", causal=False)}
+
+
+def strong_scaling(c, world, rank, dev, sync_all, iters=5):
+    """The same TOTAL problem on 1 GPU (rank 0 alone) and head-sharded over all ranks, with and without the all-gather of O."""
+    import torch.distributed as dist
+    from flash_attention_dlrs_amd import flash_attention_forward
+    from flash_attention_dlrs_amd.sharded import flash_attention_forward_sharded
+    dtype = TORCH_DTYPE[c["dtype"]]
+    spread = 0.5 if c["dtype"] == "fp8" else 1.0
+    Hs = c["H"] // world
+    torch.manual_seed(1234 + rank)
+    Q, K, V = ((torch.randn(c["B"], Hs, c["N"], c["d"], device=dev) * spread).to(dtype) for _ in range(3))
+
+    def timed(fn):
+        fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        sync_all()
+        t = torch.tensor([(time.perf_counter() - t0) / iters], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+    t_shard = timed(lambda: flash_attention_forward(Q, K, V, dev, causal=c["causal"]))
+    t_gather = timed(lambda: flash_attention_forward_sharded(Q, K, V, causal=c["causal"], gather=True))
+    del Q, K, V
+    t_one = torch.zeros(1, device=dev, dtype=torch.float64)
+    if rank == 0:   # the whole problem on one GPU, the others idle
+        Qf, Kf, Vf = ((torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev) * spread).to(dtype) for _ in range(3))
+        flash_attention_forward(Qf, Kf, Vf, dev, causal=c["causal"])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            flash_attention_forward(Qf, Kf, Vf, dev, causal=c["causal"])
+        torch.cuda.synchronize(dev)
+        t_one[0] = (time.perf_counter() - t0) / 2
+        del Qf, Kf, Vf
+    dist.all_reduce(t_one, op=dist.ReduceOp.MAX)
+    F = flops(dict(c))
+    return {"config": f"{c['name']}: B={c['B']} H={c['H']} N={c['N']} d={c['d']} {c['dtype']}, {Hs} heads per GPU",
+            "ms_1gpu_whole_problem": round(t_one.item() * 1e3, 3), "ms_sharded": round(t_shard * 1e3, 3),
+            "ms_sharded_plus_gather": round(t_gather * 1e3, 3),
+            "speedup_vs_1gpu": round(t_one.item() / t_shard, 3), "speedup_vs_1gpu_with_gather": round(t_one.item() / t_gather, 3),
+            "tflops_aggregate": round(F / t_shard / 1e12, 1), "tflops_per_gpu": round(F / t_shard / 1e12 / world, 1),
+            "tflops_aggregate_with_gather": round(F / t_gather / 1e12, 1)}
 
 
 def main():
@@ -153,9 +232,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torch.distributed.run, also at world size 1
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    grouped = dist.is_initialized()
 
     c = CONFIGS[args.config]
     dtype = TORCH_DTYPE[c["dtype"]]
@@ -164,13 +246,13 @@ def main():
     variant = args.variant
 
     def step():
-        if args.gather and world > 1:
+        if args.gather and grouped:
             return flash_attention_forward_sharded(Q, K, V, causal=c["causal"], gather=True)
         return flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant=variant)
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -193,7 +275,7 @@ def main():
         e.record()
     sync_all()
     el = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
@@ -205,7 +287,7 @@ def main():
     value = world * F / (el / args.steps) / 1e12
     peak = PEAK_TFLOPS[c["dtype"]]
     achieved = F / (kern_avg * 1e-3) / 1e12
-    tile = _lib.query_tile(c["N"], c["d"], {"bf16": 2, "fp16": 1, "f32": 0, "fp8": 4}[c["dtype"]], c["causal"])
+    tile = _lib.query_tile(c["N"], c["d"], {"bf16": 2, "fp16": 1, "f32": 0, "fp8": 4}[c["dtype"]], c["causal"], B=c["B"], H=c["H"])
 
     extras = {}
     if not args.no_extras:
@@ -243,7 +325,7 @@ def main():
                                   "launches": "D, dQ (query-block owner), dK/dV (key-block owner); deterministic"}
             del O, Ls, dO
         # (2) the optional exchange step: all-gather of the O shards over xGMI, overlapped per batch element
-        if world > 1:
+        if grouped:
             for _ in range(2):
                 flash_attention_forward_sharded(Q, K, V, causal=c["causal"], gather=True)
             sync_all()
@@ -254,8 +336,11 @@ def main():
             tg = (time.perf_counter() - t1) / 5
             o_bytes = Q.numel() * Q.element_size()
             extras["gather"] = {"included_in_step": bool(args.gather), "ms_compute_plus_gather": round(tg * 1e3, 4),
-                                "o_shard_MiB": o_bytes / 2 ** 20,
+                                "o_shard_MiB": o_bytes / 2 ** 20, "world_size": world,
                                 "tflops_with_gather": round(world * F / tg / 1e12, 2)}
+        # (3) the strong-scaling configurations BASELINE.json names for this GPU count: configs[3] on 4 GPUs, configs[4] on 8
+        if world in STRONG and grouped:
+            extras["strong_scaling"] = strong_scaling(STRONG[world], world, rank, dev, sync_all)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -264,7 +349,7 @@ def main():
     traffic = profiled_traffic(args.config, variant) if args.variant == "auto" else None
     if rank == 0:
         out = {
-            "metric": "attention fwd TFLOP/s per GPU (B=4,H=32,N=4096,d=128 bf16); % MFMA peak",
+            "metric": f"attention fwd TFLOP/s per GPU (B={c['B']},H={c['H']},N={c['N']},d={c['d']} {c['dtype']}); % MFMA peak",
             "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": c["dtype"], "data": "synthetic",
@@ -286,7 +371,7 @@ def main():
             "lib": _lib.version(),
         }
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

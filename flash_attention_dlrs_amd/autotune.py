@@ -27,9 +27,8 @@ _table = None
 
 # variants worth timing per dtype family (all covered by tests/test_fwd_parity.py)
 _CANDIDATES = {
-    "16": ("mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16s", "mfma16s_w4", "mfma16x", "mfma16p_w8", "mfma16_w8",
-           "mfma16k", "mfma16k_r2k2", "mfma16k_r2k4"),
-    "8": ("mfma8x", "mfma8x_w4", "mfma8u", "mfma8", "mfma8_w4"),
+    "16": ("a64", "mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16_w8", "mfma16k", "mfma16k_r2k2", "mfma16k_r2k4"),
+    "8": ("mfma8x", "mfma8x_w4"),
 }
 
 
@@ -73,6 +72,12 @@ def key_of(Q, causal):
     return f"{str(Q.dtype).split('.')[-1]}:d{d}:N{nb}:{'causal' if causal else 'full'}:{'large' if units >= 512 else 'small'}"
 
 
+def table_id(device):
+    """the persisted table is per device model and library version (a new kernel build re-tunes)"""
+    name = torch.cuda.get_device_name(device) if torch.device(device).type == "cuda" else "cpu"
+    return f"{name}|{_lib.version()}"
+
+
 def _time(Q, K, V, O, L, dtype_enum, causal, scale, variant, iters=5):
     for _ in range(2):
         _lib.fa2_fwd(Q, K, V, O, L, dtype_enum, causal=causal, scale=scale, variant=variant)
@@ -92,7 +97,8 @@ def pick(Q, K, V, O, L, dtype_enum, causal, scale):
         return _lib.VARIANT_AUTO
     table = _load()
     key = key_of(Q, causal)
-    if key in table and table[key]["variant"] in _lib.VARIANTS:
+    tid = table_id(Q.device)
+    if key in table and table[key]["variant"] in _lib.VARIANTS and table[key].get("table_id") == tid:
         return _lib.VARIANTS[table[key]["variant"]]
     fam = "16" if Q.dtype in (torch.float16, torch.bfloat16) else "8" if Q.element_size() == 1 else None
     if fam is None:  # fp32 / fp64: one MFMA kernel and the generic one -- nothing to choose
@@ -116,6 +122,6 @@ def pick(Q, K, V, O, L, dtype_enum, causal, scale):
     if results[best] > 0.98 * results["auto"]:
         best = "auto"
     table[key] = {"variant": best, "ms": {k: round(v, 5) for k, v in results.items()},
-                  "device": torch.cuda.get_device_name(Q.device)}
+                  "device": torch.cuda.get_device_name(Q.device), "table_id": tid}
     _save()
     return _lib.VARIANTS[best]

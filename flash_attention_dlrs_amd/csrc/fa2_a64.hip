@@ -69,9 +69,7 @@ DevState *dev_state() {
             if (e != hipSuccess) d.fn[t][c] = nullptr;  // a kernel the generator did not emit: reported at launch
         }
     (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    d.cus = n;
+    d.cus = fa2_device_cus();
     d.ready = true;
     return &d;
 }

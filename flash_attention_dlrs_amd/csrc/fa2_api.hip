@@ -53,8 +53,8 @@ int validate(const Fa2Problem &p) {
     return FA2_OK;
 }
 
-// The static tile table.  Keyed on (dtype, d, N, causal) only: unlike the reference's autotune key
-// (B, H, N, d) the choice does not depend on B or H.
+// The static tile table, keyed like the reference's autotuner on (B, H, N, d) (plus dtype, causal, strides): the grid
+// size B * H * tiles decides between the key-split, 4-wave and one-workgroup-per-CU kernels.
 int pick_variant(const Fa2Problem &p) {
     if (fa2_mfma16_supports(p)) {
         // Software-pipelined kernel with LDS-DMA staging.  8 waves x 32 rows halves the K/V traffic per query
@@ -131,14 +131,18 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16: return fa2_launch_mfma16(p, 4);
     case FA2_VARIANT_MFMA16_W8: return fa2_launch_mfma16(p, 8);
     case FA2_VARIANT_MFMA32: return fa2_launch_mfma32(p);
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16P: return fa2_launch_mfma16p(p, 4, 0);
     case FA2_VARIANT_MFMA16P_W8: return fa2_launch_mfma16p(p, 8, 64);
     case FA2_VARIANT_MFMA16X: return fa2_launch_mfma16x(p, 0);
     case FA2_VARIANT_MFMA8: return fa2_launch_mfma8(p, 8);
     case FA2_VARIANT_MFMA8_W4: return fa2_launch_mfma8(p, 4);
+#endif
     case FA2_VARIANT_MFMA8X: return fa2_launch_mfma8x(p, 8);
     case FA2_VARIANT_MFMA8X_W4: return fa2_launch_mfma8x(p, 4);
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA8U: return fa2_launch_mfma8x(p, 12);
+#endif
     case FA2_VARIANT_MFMA16K: return fa2_launch_mfma16k(p, 42);
     case FA2_VARIANT_MFMA16K_R2K2: return fa2_launch_mfma16k(p, 22);
     case FA2_VARIANT_MFMA16K_R2K4: return fa2_launch_mfma16k(p, 24);
@@ -147,6 +151,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16H: return fa2_launch_mfma16h(p, 8);
     case FA2_VARIANT_MFMA16H_W4: return fa2_launch_mfma16h(p, 4);
     case FA2_VARIANT_A64: return fa2_launch_a64(p);
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
     case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
     case FA2_VARIANT_MFMA16X + 2048 * 1: return fa2_launch_mfma16x(p, 1);   // ablations (FA2_ABLATIONS builds)
@@ -170,6 +175,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16P_W8 + 192 * 16: return fa2_launch_mfma16p(p, 8, 192);
     case FA2_VARIANT_MFMA16P_W8 + 1024: return fa2_launch_mfma16p(p, 8, 0);
     case FA2_VARIANT_MFMA16P + 1024: return fa2_launch_mfma16p(p, 4, 64);
+#endif
     default: fa2_set_error("unknown kernel variant %d", variant); return FA2_ERR_BAD_ARG;
     }
 }
@@ -204,9 +210,36 @@ void fa2_set_error(const char *fmt, ...) {
 }
 
 int fa2_env_int(const char *name, int dflt) {
+#ifdef FA2_TUNING_ENV
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
+
+namespace {
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return dev;
+}
+}  // namespace
+
+int fa2_device_cus() {
+    static int cus[64] = {0};
+    const int dev = current_device();
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+bool Fa2DeviceLatch::need() const { return !((__atomic_load_n(&done, __ATOMIC_RELAXED) >> current_device()) & 1ull); }
+void Fa2DeviceLatch::mark() { __atomic_fetch_or(&done, 1ull << current_device(), __ATOMIC_RELAXED); }
 
 extern "C" {
 
@@ -229,21 +262,23 @@ int fa2_fwd_variant(const void *Q, const void *K, const void *V, void *O, void *
 }
 
 int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int32_t out4[4]) {
+    return fa2_query_tile_ex(64, 8, N, d, dtype_enum, causal, out4);
+}
+
+int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int32_t out4[4]) {
     if (!out4) {
         fa2_set_error("out4 is null");
         return FA2_ERR_BAD_ARG;
     }
-    // A contiguous (1, 8, N, d) problem with aligned dummy pointers: only the table is consulted.
-    static const int64_t dummy = 0;
+    // A contiguous (B, H, N, d) problem with aligned dummy pointers: only the table is consulted.
     Fa2Problem p;
     memset(&p, 0, sizeof(p));
     p.Q = p.K = p.V = (const void *)0x1000;
     p.O = p.L = (void *)0x1000;
-    (void)dummy;
-    p.B = 64; p.H = 8; p.N = N; p.d = d; p.dtype = dtype_enum; p.causal = causal ? 1 : 0; p.scale = 1.0f;
-    const int64_t s[4] = {(int64_t)8 * N * d, (int64_t)N * d, d, 1};
+    p.B = B; p.H = H; p.N = N; p.d = d; p.dtype = dtype_enum; p.causal = causal ? 1 : 0; p.scale = 1.0f;
+    const int64_t s[4] = {(int64_t)H * N * d, (int64_t)N * d, d, 1};
     for (int k = 0; k < 4; ++k) p.qs[k] = p.ks[k] = p.vs[k] = p.os[k] = s[k];
-    p.ls[0] = (int64_t)8 * N; p.ls[1] = N;
+    p.ls[0] = (int64_t)H * N; p.ls[1] = N;
     const int rc = validate(p);
     if (rc != FA2_OK) return rc;
     const int v = pick_variant(p);
@@ -251,15 +286,21 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     switch (v) {
     case FA2_VARIANT_MFMA16: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16_W8: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16P: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16P_W8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16X: out4[1] = 256; out4[2] = 32; out4[3] = 4; break;
+#endif
     case FA2_VARIANT_A64: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
+#endif
     case FA2_VARIANT_MFMA8X: out4[1] = 256; out4[2] = 64; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8X_W4: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA8U: out4[1] = 128; out4[2] = 64; out4[3] = 4; break;
+#endif
     case FA2_VARIANT_MFMA16K: out4[1] = 128; out4[2] = 64; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16K_R2K2: out4[1] = 64; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16K_R2K4: out4[1] = 64; out4[2] = 64; out4[3] = 8; break;
@@ -267,8 +308,10 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
     case FA2_VARIANT_MFMA16D_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     case FA2_VARIANT_MFMA16H: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16H_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
+#ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16S: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA16S_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
+#endif
     case FA2_VARIANT_MFMA32: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;
     default: out4[1] = 16; out4[2] = 64; out4[3] = 4; break;
     }

@@ -534,10 +534,10 @@ template <typename T, int D> int launch_d(const Fa2BwdProblem &p, const BArgs &a
     } else {
         hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 1, 4>), dim3((unsigned)nblk), dim3(256), smem1, p.stream, a);
     }
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation
-    if (!attr_set) {
+    static Fa2DeviceLatch attr_set;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute((const void *)bwd_mfma16_kernel<T, D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem0);
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((bwd_mfma16_kernel<T, D, 0>), dim3((unsigned)nblk), dim3(512), smem0, p.stream, a);
     const hipError_t e = hipGetLastError();

@@ -292,10 +292,10 @@ template <int D> int launch_d(const Fa2BwdProblem &p, const B32Args &a) {
         return FA2_ERR_BAD_ARG;
     }
     constexpr size_t smem0 = 4 * 32 * D * 4 + 4 * 32 * 4, smem1 = 4 * 32 * D * 4;
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS (d = 128, key-owner launch) needs the attribute
-    if (!attr_set) {
+    static Fa2DeviceLatch attr_set;  // > 64 KiB of dynamic LDS (d = 128, key-owner launch) needs the attribute
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute((const void *)bwd_mfma32_kernel<D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem0);
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((bwd_mfma32_kernel<D, 1>), dim3((unsigned)nblk), dim3(256), smem1, p.stream, a);  // leaves Lc
     hipLaunchKernelGGL((bwd_mfma32_kernel<D, 0>), dim3((unsigned)nblk), dim3(256), smem0, p.stream, a);

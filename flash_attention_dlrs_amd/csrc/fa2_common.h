@@ -21,13 +21,16 @@ struct Fa2Problem {
 int fa2_launch_generic(const Fa2Problem &p);
 int fa2_launch_mfma16(const Fa2Problem &p, int waves);
 int fa2_launch_mfma32(const Fa2Problem &p);
-int fa2_launch_mfma16p(const Fa2Problem &p, int waves, int opt);
-int fa2_launch_mfma16x(const Fa2Problem &p, int abl);
 int fa2_launch_mfma16d(const Fa2Problem &p, int waves);
-int fa2_launch_mfma8(const Fa2Problem &p, int waves);
 int fa2_launch_mfma8x(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16k(const Fa2Problem &p, int shape);
+#ifdef FA2_EXPERIMENTS   // libfa2_hip_exp.so only (fa2_experiments.h)
+#include "fa2_experiments.h"
+int fa2_launch_mfma16p(const Fa2Problem &p, int waves, int opt);
+int fa2_launch_mfma16x(const Fa2Problem &p, int abl);
+int fa2_launch_mfma8(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16s(const Fa2Problem &p, int waves);
+#endif
 int fa2_launch_mfma16h(const Fa2Problem &p, int waves);  // dispatches to the two translation units below
 int fa2_launch_mfma16h_causal(const Fa2Problem &p, int waves);
 int fa2_launch_mfma16h_noncausal(const Fa2Problem &p, int waves);
@@ -39,7 +42,18 @@ bool fa2_mfma16_supports(const Fa2Problem &p);
 bool fa2_mfma32_supports(const Fa2Problem &p);
 
 void fa2_set_error(const char *fmt, ...);
-int fa2_env_int(const char *name, int dflt);  // tuning knobs for A/B runs (read per call)
+// Tuning knobs for A/B runs.  The product build returns `dflt` without touching the environment (no getenv on the launch
+// path); `make experiments` (-DFA2_TUNING_ENV) reads the variable per call.
+int fa2_env_int(const char *name, int dflt);
+
+// Per-DEVICE launch state (a process may drive several GPUs): the CU count of the current device, and a once-per-device
+// latch for hipFuncSetAttribute(MaxDynamicSharedMemorySize) -- function attributes are per device.
+int fa2_device_cus();
+struct Fa2DeviceLatch {
+    unsigned long long done = 0;  // bit d: applied on device d (a racing second application is harmless: idempotent)
+    bool need() const;            // true if the current device has not been marked yet
+    void mark();
+};
 
 static inline int fa2_dtype_size(int dt) {
     switch (dt) {

@@ -657,22 +657,17 @@ template <typename T, int D, int NW> int launch_t(const Fa2Problem &p, const Dma
         return FA2_ERR_BAD_ARG;
     }
     // persistent grid: one workgroup per CU (8 waves) or two (4 waves), a multiple of 8 (XCD affinity of the units)
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
+    const int cus = fa2_device_cus();
     long long slots = (long long)cus * (NW == 8 ? 1 : 2) * fa2_env_int("FA2_WG_PER_SLOT", 1);
     slots -= slots % 8;
     if (slots < 8) slots = 8;
     const dim3 grid((unsigned)(nunits < slots ? nunits : slots)), block(NW * 64);
     constexpr size_t smem = 4 * 64 * D * 2 + (NW == 8 ? NW * 32 * D * 2 : 0);  // K/V ring (+ epilogue slices)
     auto launch = [&](auto kern) __attribute__((always_inline)) {
-        static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation
-        if (!attr_set) {
+        static Fa2DeviceLatch attr;  // > 64 KiB of dynamic LDS needs the attribute; once per instantiation AND device
+        if (attr.need()) {
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr_set = true;
+            attr.mark();
         }
         hipLaunchKernelGGL(kern, grid, block, smem, p.stream, a);
     };

@@ -324,11 +324,11 @@ template <typename T, int D, int RB, int KG> int launch_t(const Fa2Problem &p, c
     const dim3 grid((unsigned)nblk), block(RB * KG * 64);
     constexpr size_t smem = KG * 4 * 64 * D * 2;
     static_assert(smem <= 160 * 1024, "tile buffers exceed the LDS");
-    static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in (idempotent, racing is harmless)
-    if (!attr_done) {
+    static Fa2DeviceLatch attr_done;  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation and device
+    if (attr_done.need()) {
         (void)hipFuncSetAttribute((const void *)fa2_fwd_mfma16k_kernel<T, D, RB, KG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void *)fa2_fwd_mfma16k_kernel<T, D, RB, KG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
+        attr_done.mark();
     }
     if (p.causal)
         hipLaunchKernelGGL((fa2_fwd_mfma16k_kernel<T, D, RB, KG, true>), grid, block, smem, p.stream, a);

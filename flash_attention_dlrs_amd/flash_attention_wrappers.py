@@ -30,9 +30,19 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
     L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=dev)
 
     dtype = convert_triton_dtype(Q.dtype)
+    if O.device != Q.device:   # the launch runs on Q's device: an O allocated elsewhere would be a foreign pointer there
+        raise ValueError(f"dev={dev} is not the device of Q, K, V ({Q.device})")
     v = _lib.VARIANTS[variant]
     if variant == "auto" and autotune.enabled():
         v = autotune.pick(Q, K, V, O, L, dtype, causal, scale)  # the on-box tuner, FA2_AUTOTUNE=1
+        if v != _lib.VARIANT_AUTO:
+            try:
+                _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
+                return (O if d_pow == d else O[:, :, :, 0:d]), L
+            except TypeError:
+                # the tuned variant cannot run THIS problem (strides, alignment, N * stride >= 2 GiB: the tuner's key does
+                # not see them): the static table can, it falls back to the kernels that take any layout
+                v = _lib.VARIANT_AUTO
     _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
 
     return (O if d_pow == d else O[:, :, :, 0:d]), L

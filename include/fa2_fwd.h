@@ -48,30 +48,23 @@ extern "C" {
  * replaces the reference's run-time autotuner (src/autotune_configs.py:24-201, kernels.py:11-15). */
 #define FA2_VARIANT_AUTO 0
 #define FA2_VARIANT_GENERIC 1 /* any dtype, any strides, d = 2^k in [16,512], any N; FMA on VALU  */
-#define FA2_VARIANT_MFMA16 2  /* f16/bf16, d in {64,128}, unit d-stride; 4 waves x 32 rows         */
+#define FA2_VARIANT_MFMA16 2  /* f16/bf16, d in {64,128}, unit d-stride; 4 waves x 32 rows (the fallback when N * row     */
+                              /* stride does not fit 32-bit buffer offsets)                                           */
 #define FA2_VARIANT_MFMA16_W8 3 /* same, 8 waves x 32 rows (256-row Q tile)                        */
 #define FA2_VARIANT_MFMA32 4  /* f32 via v_mfma_f32_32x32x2_f32, d in {64,128}                     */
-#define FA2_VARIANT_MFMA16P 5 /* f16/bf16 software-pipelined (32-key blocks, QK^T of block j+1 under   */
-                              /* the softmax of block j), 4 waves x 32 rows                         */
-#define FA2_VARIANT_MFMA16P_W8 6 /* same, 8 waves x 32 rows                                         */
-#define FA2_VARIANT_MFMA16D 8 /* MFMA16P_W8 with LDS-DMA staging (buffer_load ... lds), 8 waves x 32 rows  */
+#define FA2_VARIANT_MFMA16D 8 /* f16/bf16 software-pipelined (32-key blocks), LDS-DMA staging (buffer_load ... lds), 8 waves x 32 rows */
 #define FA2_VARIANT_MFMA16D_W4 9 /* same, 4 waves x 32 rows                                          */
-#define FA2_VARIANT_MFMA8 10  /* fp8 (e4m3fn / e5m2), d = 128, v_mfma_f32_32x32x16_fp8_fp8 / bf8_bf8; 8 waves    */
-#define FA2_VARIANT_MFMA8_W4 11 /* same, 4 waves x 32 rows                                            */
-#define FA2_VARIANT_MFMA16S 12 /* MFMA16D on v_mfma_f32_16x16x32 (d = 128): no lane exchange in the loop; 8 waves x 32 rows */
-#define FA2_VARIANT_MFMA16S_W4 13 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA16H 14 /* MFMA16D with a persistent grid, next-job prefetch and a hand-ordered steady loop; 8 waves */
 #define FA2_VARIANT_MFMA16H_W4 15 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA8X 16 /* fp8 on the double-rate v_mfma_f32_32x32x64_f8f6f4: 64-key units, 8 waves x 32 rows       */
 #define FA2_VARIANT_MFMA8X_W4 17 /* same, 4 waves x 32 rows                                          */
-#define FA2_VARIANT_MFMA8U 18 /* MFMA8X_W4 unpipelined at <= 168 registers: three workgroups (12 waves) per CU            */
 #define FA2_VARIANT_MFMA16K 19 /* f16/bf16 small grids: 8 waves on a 128-row tile, waves w and w+4 split the KEYS and merge through LDS */
 #define FA2_VARIANT_MFMA16K_R2K2 20 /* same with a 64-row tile: 2 row blocks x 2 key groups, four waves                    */
 #define FA2_VARIANT_MFMA16K_R2K4 23 /* 64-row tile, 2 row blocks x 4 key groups, eight waves (d = 64)                       */
 #define FA2_VARIANT_A64 24 /* f16/bf16, d = 128, N % 256 == 0: generated gfx950 assembly, 4 waves x 64 rows, one wave per SIMD   */
-                           /* with the whole register file (O, Q, K in AGPRs), persistent grid                              */
-#define FA2_VARIANT_MFMA16X 7 /* f16/bf16, d = 128: 4 waves x 64 rows, one wave per SIMD, every K/V    */
-                              /* fragment read from LDS feeds two MFMAs                              */
+                           /* with the whole register file (O, Q, V^T in AGPRs), persistent grid, continuous tile stream      */
+/* (ids 5-7, 10-13, 18 and the ablation ids belong to experimental kernels that are not part of this library:
+ *  flash_attention_dlrs_amd/csrc/fa2_experiments.h, `make -C flash_attention_dlrs_amd/csrc experiments`) */
 
 /*
  * O = softmax(scale * Q K^T [+ causal mask]) V   and   L = log2-domain log-sum-exp of the scores,
@@ -100,6 +93,11 @@ int fa2_fwd_variant(const void *Q, const void *K, const void *V, void *O, void *
 /* Which tile the static table picks for a contiguous problem: out4 = {variant, B_r, B_c, waves}.
  * Counterpart of fwd_conf_prune + the autotuner's choice (src/autotune_configs.py:176-194). */
 int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int32_t out4[4]);
+
+/* The table's choice depends on the grid size (B * H tiles must fill 256 CUs): fa2_query_tile answers for a large grid
+ * (B = 64, H = 8), fa2_query_tile_ex for the given B and H -- the variant fa2_fwd() runs for that contiguous problem. */
+int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal,
+                      int32_t out4[4]);
 
 /* "fa2-hip <semver> gfx950". */
 const char *fa2_version(void);

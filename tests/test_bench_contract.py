@@ -44,3 +44,16 @@ def test_distributed_launcher_world1():
               "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "1", "--steps", "3",
               "--warmup", "1", "--no-cpu-baseline", "--gather"])
     assert j["n_gpus"] == 1 and j["value"] > 0
+    # launched by torch.distributed.run the bench initialises the nccl (= RCCL) group even at world size 1 and --gather puts
+    # the all-gather of O into the step
+    g = j["extras"]["gather"]
+    assert g["included_in_step"] is True and g["world_size"] == 1 and g["ms_compute_plus_gather"] > 0
+
+
+def test_query_tile_reports_the_variant_the_launch_takes():
+    from flash_attention_dlrs_amd import _lib
+    # c2 (B2 H8 N1024 d64 fp16) is a small grid: the key-split kernel, not the large-grid answer
+    assert _lib.query_tile(1024, 64, _lib.FA2_DTYPE_F16, False, B=2, H=8)[0] == _lib.VARIANT_MFMA16K_R2K4
+    assert _lib.query_tile(4096, 128, _lib.FA2_DTYPE_BF16, True, B=4, H=32)[0] == _lib.VARIANT_A64
+    j = _run([sys.executable, "bench.py", "--config", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert j["config"]["tile"]["variant"] == _lib.VARIANT_MFMA16K_R2K4 and "N=1024" in j["metric"]

@@ -48,7 +48,7 @@ def test_random_shape(B, H, N, d, dtype, causal):
     O_t, g_t = truth(Q, K, V, dO, causal)
     fwd_variants = ["auto", "generic"]
     if dtype != torch.float32 and d in (64, 128):
-        fwd_variants += ["mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16k", "mfma16k_r2k2"] + (["mfma16x", "mfma16s"] if d == 128 else ["mfma16k_r2k4"])
+        fwd_variants += ["mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16k", "mfma16k_r2k2"] + ([] if d == 128 else ["mfma16k_r2k4"])
     if dtype == torch.float32 and d in (64, 128):
         fwd_variants += ["mfma32"]
     for v in fwd_variants:

@@ -103,13 +103,16 @@ def test_autotune_key_and_table_roundtrip(tmp_path, monkeypatch):
     path = str(tmp_path / "t.json")
     autotune.enable(True, path)
     try:
-        autotune._load()["bfloat16:d128:N4096:causal:large"] = {"variant": "mfma16d", "ms": {}}
+        autotune._load()["bfloat16:d128:N4096:causal:large"] = {"variant": "mfma16d", "ms": {}, "table_id": autotune.table_id("cpu")}
         autotune._save()
         autotune.enable(True, path)  # drops the in-memory copy
         assert autotune._load()["bfloat16:d128:N4096:causal:large"]["variant"] == "mfma16d"
         # a known key is answered from the table without touching the GPU
         Q = q(4, 32, 4096, 128)
         assert autotune.pick(Q, Q, Q, Q, Q, _lib.FA2_DTYPE_BF16, True, 1.0) == _lib.VARIANT_MFMA16D
+        # an entry tuned on another device model or library version is not served
+        autotune._load()["bfloat16:d128:N4096:causal:large"]["table_id"] = "some other GPU|fa2-hip 0.0.0"
+        assert "table_id" in autotune._load()["bfloat16:d128:N4096:causal:large"]
     finally:
         autotune.enable(False)
     Q = q(4, 32, 4096, 128)
