@@ -25,6 +25,33 @@ def wait_states(ins: Inst) -> int:
     return 1
 
 
+REQUIRED = {"R1": 12, "R2": 2, "R3": 1, "R4": 2, "R5": 1, "R6": 5, "R7": 1, "R8": 12}
+
+
+def fix(prog, max_rounds=64):
+    """What a compiler's hazard recognizer does: insert `s_nop` in front of every instruction that violates a wait-state rule.
+    Returns (new program, number of wait states inserted).  In the densely scheduled loop nothing is inserted; the sparse
+    code around it (pipeline fill, rare paths) gets its pads here instead of by hand."""
+    prog = list(prog)
+    added = 0
+    for _ in range(max_rounds):
+        errs = check(prog, verbose=False)
+        if not errs:
+            return prog, added
+        need = {}
+        for idx, rule, _, dist in errs:
+            need[idx] = max(need.get(idx, 0), REQUIRED[rule.split()[0]] - dist)
+        for idx in sorted(need, reverse=True):
+            n = need[idx]
+            added += n
+            pads = []
+            while n > 0:
+                pads.append(Inst("s_nop", (min(n, 16) - 1,), {}, "wait states (check.fix)"))
+                n -= min(n, 16)
+            prog[idx:idx] = pads
+    raise RuntimeError("hazard fixer did not converge")
+
+
 def check(prog, verbose=True):
     last_mfma_def = {}    # reg -> (pos, inst index, dst-range tuple)
     last_mfma_csrc = {}   # reg -> pos (read as C by an MFMA)

@@ -623,6 +623,38 @@ class Workgroup:
             row = (reg & 3) + 8 * (reg >> 2)
             w.wr_v(d, np.concatenate([Dm[row, :], Dm[row + 4, :]]), reg, masked=False)
 
+    def _mfma16(self, w, i, decode):
+        """v_mfma_f32_16x16x32: A[m = l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][n = l & 15], D[m = 4 (l >> 4) + r][n = l & 15]"""
+        d, a, b, c = i.ops
+
+        def mat(o):  # -> [16][32]: row l & 15, k = 8 (l >> 4) + j
+            m = np.zeros((16, 32), np.float64)
+            for reg in range(4):
+                u = w.rd_v(o, reg)
+                for half in range(2):
+                    vals = decode(((u >> (16 * half)) & 0xFFFF).astype(np.uint16)).astype(np.float64)
+                    j = 2 * reg + half
+                    for g in range(4):
+                        m[:, 8 * g + j] = vals[16 * g:16 * g + 16]
+            return m
+        Am = mat(a)
+        Bm = mat(b).T  # [32][16]
+        Cm = np.zeros((16, 16), np.float64)
+        if isinstance(c, Reg):
+            for reg in range(4):
+                x = w.rd_v(c, reg).view(np.float32).astype(np.float64)
+                for g in range(4):
+                    Cm[4 * g + reg, :] = x[16 * g:16 * g + 16]
+        Dm = (Am @ Bm + Cm).astype(np.float32)
+        for reg in range(4):
+            w.wr_v(d, np.concatenate([Dm[4 * g + reg, :] for g in range(4)]), reg, masked=False)
+
+    def x_v_mfma_f32_16x16x32_bf16(self, w, i):
+        self._mfma16(w, i, bf16_to_f32)
+
+    def x_v_mfma_f32_16x16x32_f16(self, w, i):
+        self._mfma16(w, i, lambda u: u.view(np.float16).astype(np.float32))
+
     def x_v_mfma_f32_32x32x16_bf16(self, w, i):
         self._mfma(w, i, bf16_to_f32)
 

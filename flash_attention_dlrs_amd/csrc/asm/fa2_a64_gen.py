@@ -42,7 +42,7 @@ V_KRE, V_KRO = 192, 193   # K row-read lane bases (even / odd k-step)
 V_VR0, V_VR1 = 194, 195   # V transposed-read lane bases (u = 0 / 1), the V ring's LDS offset included
 V_DKO, V_DVO = 196, 197   # LDS-DMA per-lane source offsets (K / V row stride)
 V_MC = (198, 199)         # running row maximum in the exp2 domain (c * max), per query block
-V_RS = ((200, 201), (202, 203))  # row-sum accumulators [qb][2]
+V_RS = ((200, 201), (202, 203))  # (unused: the row sums live in V_LACC)
 V_MX = ((204, 205), (206, 207))  # row-max chains [qb][kb]
 V_CO = (208, 209)         # rescale coefficient per query block
 V_T = tuple(range(210, 220))     # temporaries (V_T[2] = v212 is 4-aligned: a zero MFMA operand in the epilogue)
@@ -55,8 +55,10 @@ V_EO = 225                # epilogue global store lane offset (os_n)
 V_L2 = 226                # L store lane offset
 V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), accumulators [4] (228..231)
 V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
-V_LSV = (234, 235)        # row sums of the finished job, saved for its epilogue
+V_LSV = (234, 235)        # scratch (Q prefetch experiments)
 V_MSV = (236, 237)        # running maximum of the finished job
+V_ONES = 244              # 4 registers: the 0 / 1 A operand of the row-sum MFMA (v_mfma_f32_16x16x32)
+V_LACC = (248, 252)       # row-sum accumulators of the two query blocks (4 registers each; register 0 = the lane's own row)
 V_DQE, V_DQO = 240, 241   # LDS-DMA per-lane source offsets of the Q rows (row stride qs_n; even / odd 8-row group)
 V_QRE, V_QRO = 242, 243   # Q row-read lane bases in the wave's slice (even / odd k-step)
 V_IMH = 238               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
@@ -137,6 +139,7 @@ class Gen:
         self.R, self.dk, self.dv = ring   # ring depth; K(t + dk) and V(t + dv) are streamed in phase B(t): dk <= R + 1, dv <= R
         assert 3 <= self.dk <= min(self.R + 1, 4) and 2 <= self.dv <= self.R and 4 % self.R == 0
         self.vm = 8 * min(self.dk - 3, self.dv - 2)  # DMA pieces that may stay in flight across the mid-step barrier
+        self._cache = {}
         self.stamps = stamps   # diagnostic build: s_memtime stamps of the job timeline go to the debug buffer
 
     # ------------------------------------------------------------------ small helpers
@@ -289,6 +292,14 @@ class Gen:
               I("s_add_u32", S_DBG.sub(0), S_DBG.sub(0), S_T[0]), I("s_addc_u32", S_DBG.sub(1), S_DBG.sub(1), 0))
             e(self.stamp(6, real=True), self.stamp(8))
             e([I("v_mov_b32", V(V_ST_ACC + k), 0) for k in range(4)], I("v_mov_b32", V(V_ST_LAST), 0))
+        # ---- row sums on the matrix pipe: the 0 / 1 operand (lanes with (lane & 7) == 4 * ((lane >> 4) & 1) hold ones), accumulators
+        one2 = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
+        e(comment("row-sum MFMA operand, accumulators, rescale factors"),
+          I("v_bfe_u32", t1, lane, 4, 1), I("v_lshlrev_b32", t1, 2, t1), I("v_and_b32", t0, 7, lane),
+          I("v_cmp_eq_u32", VCC, t0, t1), I("v_mov_b32", t2, one2))
+        e([I("v_cndmask_b32", V(V_ONES + k), 0, t2, VCC) for k in range(4)])
+        e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
+        e([I("v_mov_b32", V(V_CO[qb]), 1.0) for qb in range(2)])
         # ---- scalar constants
         e(I("s_lshl_b32", S_K32, S_KSN, 5), I("s_lshl_b32", S_V32, S_VSN, 5),
           I("s_lshl_b32", S_K64, S_KSN, 6), I("s_lshl_b32", S_V64, S_VSN, 6),
@@ -494,209 +505,304 @@ class Gen:
                 out.append(I("ds_read_b128", A_K(kb, ks), V(V_KRO if ks & 1 else V_KRE), offset=imm, tag=f"kread kb{kb} ks{ks}"))
         return out
 
-    def finish_ops(self, X, skip_exp=0):
-        """finish-softmax of the tile in score buffer X: exp2 (elements >= skip_exp; the first skip_exp were done in the
-        previous phase B), row sums, in-place pack.  Returns [(element index, [exp], [add], [cvt or None])]"""
-        ops = []
-        for g in range(4):
-            qb = g >> 1
-            for r in range(16):
-                el = 16 * g + r
-                x = V(X + el)
-                ex = [] if el < skip_exp else [I("v_exp_f32", x, x, tag=f"exp {el}")]
-                ad = [I("v_add_f32", V(V_RS[qb][r & 1]), V(V_RS[qb][r & 1]), x, tag=f"sum {el}")]
-                cv = []
-                if r & 1:
-                    cv = [I(self.cvt, V(X + 16 * g + (r >> 1)), V(X + el - 1), x, tag=f"cvt {el}")]
-                ops.append((el, ex, ad, cv))
-        return ops
+    # ------------------------------------------------------------------ the softmax of one tile as a list of placed operations
+    # Time line of a tile, in MFMA gaps (tau): [0, 32) = the phase A that computes its scores (QK^T chains g = 0..3, eight
+    # MFMAs each), [32, 32 + NB) = the following phase B (NB = 40 MFMAs: P.V of the previous tile plus its row sums),
+    # [32 + NB, 64 + NB) = the next phase A, at whose end P must be packed (its own P.V follows).  In steady state the
+    # physical gap (tau mod PERIOD) therefore carries operations of two tiles: a modulo reservation table keeps every gap
+    # within what hides beside an MFMA (measured, scripts/probes/mb_run + asm/microbench.py: at most five fillers per gap,
+    # issue costs v_exp 8 / three-operand VALU 5 / two-operand 4 summing to <= 24; LDS reads first in their gap).
+    NB = 40
+    PERIOD = 72
+    T_END = 104
 
-    def phase_a(self, t4, with_qk=True, with_finish=True, cinit=None, steady=False):
-        """A(t), t4 = t & 3: QK^T(t+1) -> S[1-p]  ||  finish(S[p])  ||  V(t) reads from VB[t4]"""
-        p = t4 & 1
-        X, Y = SBUF[p], SBUF[1 - p]
-        mf = self.qk_mfmas(Y, cinit) if with_qk else []
-        fill = []
-        abl = self.abl if steady else set()
-        if with_finish:
-            vr = self.v_reads(t4 % self.R)
-            for k, ins in enumerate(vr):           # 2 reads per gap over the first 16 gaps
-                if "novread" not in abl:
-                    fill.append((k * 0.5, [ins]))
-            fin = self.finish_ops(X, self.nexp_b) if "nofinish" not in abl else []
-            n = len(fin)
-            span = 31.0
-            for k, (el, ex, ad, cv) in enumerate(fin):
-                pos = k * span / n
-                if ex:
-                    fill.append((pos, ex))
-                fill.append((pos + 1.2, ad))
-                if cv:
-                    fill.append((pos + 1.4, cv))
-        if not mf:
-            return [x for _, ins in sorted(fill, key=lambda f: f[0]) for x in ins]
-        return self.interleave(mf, fill)
+    def tile_plan(self, init=False, lean=False):
+        """placement of the per-tile softmax operations: returns [(tau, kind, payload)] sorted by tau.
+        kinds: 'mx' (g, j)  'dec' (qb, part)  'f' e  'e' e  'cv' (g, j)"""
+        key = ("plan", init)
+        if key in self._cache:
+            return self._cache[key]
+        P = self.PERIOD
+        slots = [0.0] * P
+        cost = [0.0] * P
+        nexp = [0] * P
+        cap_s = [5.0] * P
+        cap_c = [24.0] * P
+        # phase B: the gap behind a 16x16x32 row-sum MFMA is half as long
+        for b in self.b_short_gaps():
+            cap_s[32 + b], cap_c[32 + b] = 2.0, 8.0
+        # pre-reserved: one V transposed read per phase-A gap; K reads, DMA pieces and their scalar set-up in phase B
+        for g in range(32):
+            slots[g] += 1
+            cost[g] += 2
+        for b, n in self.b_reserved().items():
+            slots[32 + b] += n
+            cost[32 + b] += 3 * n
+        placed = []
 
-    def max_ops(self, Y):
-        """row-max chains of the four score groups, interleaved so that no instruction waits on its predecessor; group 3's
-        chain (whose MFMAs ended phase A) starts late (MFMA result -> VALU read needs 12 wait states)"""
-        chains = []
+        def place(earliest, c, kind, payload, is_exp=False):
+            t = int(earliest)
+            while True:
+                assert t < self.T_END + 40, (kind, payload)
+                g = t % P
+                if slots[g] + 1 <= cap_s[g] and cost[g] + c <= cap_c[g] and (not is_exp or nexp[g] < 2):
+                    slots[g] += 1
+                    cost[g] += c
+                    nexp[g] += int(is_exp)
+                    placed.append((t, kind, payload))
+                    return t
+                t += 1
+        # row maxima: chain g may start 3 gaps after its last QK^T MFMA (12 wait states), one operation per gap and chain
+        t_mx = {}
         for g in range(4):
+            t = 8 * g + 11
+            for j in range(8):
+                t = place(t, 5, "mx", (g, j)) + 1
+            t_mx[g] = t
+        t_dec = {}
+        for qb in range(2):
+            t = max(t_mx[2 * qb], t_mx[2 * qb + 1])
+            nparts = 3 if init else 4
+            for part in range(nparts):
+                t = place(t, (9, 5, 9, 9)[part], "dec", (qb, part)) + 1
+            t_dec[qb] = t
+        # s' = s * c - m, exp2, pack -- element order inside a group is the packing order
+        for qb in range(2):
+            t_f = t_dec[qb]
+            last_cv = {}
+            for g in (2 * qb, 2 * qb + 1):
+                t_e_prev = None
+                for r in range(16):
+                    e = 16 * g + r
+                    tf = place(t_f, 5, "f", e)
+                    t_f = tf  # keep the fma stream in order (several per gap allowed)
+                    te = place(tf + 1, 8, "e", e, is_exp=True)
+                    if r & 1:
+                        j = r >> 1
+                        tc = max(te, t_e_prev) + 1
+                        if j - 1 in last_cv.get(g, {}):
+                            tc = max(tc, last_cv[g][j - 1] + 0)
+                        tc = place(tc, 5, "cv", (g, j))
+                        last_cv.setdefault(g, {})[j] = tc
+                    t_e_prev = te
+        placed.sort(key=lambda x: x[0])
+        assert max(t for t, _, _ in placed) < self.T_END, max(t for t, _, _ in placed)
+        self._cache[key] = placed
+        return placed
+
+    def b_short_gaps(self):
+        """indices (0..39) of the phase-B gaps that follow a 16x16x32 row-sum MFMA"""
+        return [10 * k + 8 for k in range(4)] + [10 * k + 9 for k in range(4)]
+
+    def b_reserved(self):
+        """phase-B gap -> number of pre-reserved fillers (K reads, DMA loads, DMA scalar set-up)"""
+        r = {}
+        for k in range(16):
+            r[self.b_kread_gap(k)] = r.get(self.b_kread_gap(k), 0) + 1
+        for k in range(8):
+            g = self.b_dma_gap(k)
+            r[g] = r.get(g, 0) + 1
+            r[g - 1] = r.get(g - 1, 0) + 1
+        return r
+
+    def b_kread_gap(self, k):
+        g = 2 * k
+        while g in self.b_short_gaps():
+            g += 1
+        return g
+
+    def b_dma_gap(self, k):
+        """phase-B gap whose FIRST filler is DMA piece k's load; its scalar set-up (soffset, M0) ends the gap before, so the MFMA
+        between them is the wait state the M0 write needs.  Distinct, two apart, clear of the short row-sum gaps."""
+        return (11, 13, 15, 17, 21, 23, 25, 27)[k]
+
+    def tile_op(self, Sb, kind, payload, init):
+        """the instructions of one placed operation, for the tile whose scores live in score buffer Sb"""
+        if kind == "mx":
+            g, j = payload
             qb, kb = g >> 1, g & 1
             mx = V(V_MX[qb][kb])
-            y = lambda r, g=g: V(Y + 16 * g + r)
-            ops = [I("v_max3_f32", mx, y(0), y(1), y(2), tag=f"max g{g}")]
-            for r in range(3, 15, 2):
-                ops.append(I("v_max3_f32", mx, mx, y(r), y(r + 1), tag=f"max g{g}"))
-            ops.append(I("v_max_f32", mx, mx, y(15), tag=f"max g{g}"))
-            chains.append(ops)
+            y = lambda r: V(Sb + 16 * g + r)
+            if j == 0:
+                return [I("v_max3_f32", mx, y(0), y(1), y(2), tag=f"max g{g}")]
+            if j == 7:
+                return [I("v_max_f32", mx, mx, y(15), tag=f"max g{g}")]
+            return [I("v_max3_f32", mx, mx, y(2 * j + 1), y(2 * j + 2), tag=f"max g{g}")]
+        if kind == "dec":
+            qb, part = payload
+            a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
+            d = V(V_T[qb])
+            if part == 0:
+                return [I("v_max_f32", a, a, b), I("v_mov_b32", b, a)]
+            if part == 1:
+                return [I("v_permlane32_swap_b32", a, b)]
+            if part == 2:
+                if init:
+                    return [I("v_max_f32", a, a, b), I("v_mul_f32", V(V_MC[qb]), S_C, a)]
+                return [I("v_max_f32", a, a, b), I("v_fma_f32", d, a, S_C, -V(V_MC[qb]))]
+            l_fire, l_back = self.lab("fire"), self.lab("fire_back")
+            # rare: raise this query block's running maximum now (every s' = s * c - m of the PREVIOUS tile has been formed:
+            # plan order), remember the factor; O and the row sums are scaled at the end of the coming phase B
+            t2, t3 = V(V_T[2 + 2 * qb]), V(V_T[3 + 2 * qb])
+            self.ool.append([label(l_fire), I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
+                             I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
+                             I("s_mov_b32", S_FLAG, 1), I("s_branch", Label(l_back))])
+            return [I("v_cmp_gt_f32", VCC, d, S_THR), I("s_cbranch_vccnz", Label(l_fire)), label(l_back)]
+        if kind == "f":
+            e = payload
+            y = V(Sb + e)
+            return [I("v_fma_f32", y, y, S_C, -V(V_MC[e >> 5]), tag=f"fma {e}")]
+        if kind == "e":
+            y = V(Sb + payload)
+            return [I("v_exp_f32", y, y, tag=f"exp {payload}")]
+        if kind == "cv":
+            g, j = payload
+            return [I(self.cvt, V(Sb + 16 * g + j), V(Sb + 16 * g + 2 * j), V(Sb + 16 * g + 2 * j + 1), tag=f"cvt g{g} {j}")]
+        raise KeyError(kind)
+
+    def tile_fill(self, Sb, lo, hi, init, masks=None):
+        """[(gap - lo, [insts], is_exp)] of the tile's operations with lo <= tau < hi.  masks: causal (jd, cond) -> the masking
+        tests of score group g go in front of its first row-maximum operation"""
         out = []
-        idx = [0, 0, 0, 0]
-        while any(idx[g] < len(chains[g]) for g in range(4)):
-            for g in range(4):
-                if g == 3 and len(out) < 14 and any(idx[k] < len(chains[k]) for k in range(3)):
-                    continue
-                if idx[g] < len(chains[g]):
-                    out.append(chains[g][idx[g]])
-                    idx[g] += 1
+        seen_mask = set()
+        for t, kind, payload in self.tile_plan(init):
+            if not (lo <= t < hi):
+                continue
+            ins = self.tile_op(Sb, kind, payload, init)
+            if masks is not None and kind == "mx" and payload[1] == 0 and payload[0] not in seen_mask:
+                seen_mask.add(payload[0])
+                ins = self.mask_tests(Sb, payload[0], *masks) + ins
+            out.append((t - lo, ins, kind == "e"))
         return out
 
-    def mask_block(self, Y, jd, cond=None):
-        """causal: the tile whose softmax starts in this phase B is diagonal tile jd (0..3) of its job: keys 64 jd .. 64 jd + 63 of
-        the 256-key diagonal span against this wave's rows 64 w .. 64 w + 63.  w > jd: nothing; w == jd: score groups
-        (qb0, kb0) and (qb1, kb1) get the triangle (key > query -> -inf), (qb0, kb1) is all -inf; w < jd: all -inf.
-        Register r of a group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i.  cond: (sgpr, value) extra run-time
-        condition (the tile is diagonal at all).  Returns the in-line test; the masking runs out of line."""
+    # ------------------------------------------------------------------ causal masks
+    def mask_tests(self, Y, g, jd, cond=None):
+        """causal: the tile whose softmax starts is diagonal tile jd (0..3) of its job: keys 64 jd .. 64 jd + 63 of the 256-key
+        diagonal span against this wave's rows 64 w .. 64 w + 63.  w > jd: nothing; w == jd: score groups (qb0, kb0) and
+        (qb1, kb1) get the triangle (key > query -> -inf), (qb0, kb1) is all -inf; w < jd: all -inf.  Register r of a
+        group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i.  cond: (sgpr, value): the tile is diagonal at all.
+        Returns the in-line tests for score group g (in front of its first row-maximum operation); the masking itself runs
+        out of line and opens with the MFMA -> VALU wait states."""
         l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
         out = []
         if cond is not None:
             out += [I("s_cmp_lg_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_back))]
-        out += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
+        ninf = V(V_NINF)
+        eq_ops = []
+        if g in (0, 3):
+            for r in range(16):
+                key = (r & 3) + 8 * (r >> 2)
+                eq_ops += [I("v_cmp_lt_i32", VCC, V(V_IMH), key), I("v_cndmask_b32", V(Y + 16 * g + r), V(Y + 16 * g + r), ninf, VCC)]
+        elif g == 1:
+            eq_ops = [I("v_mov_b32", V(Y + 16 + r), ninf) for r in range(16)]
+        if eq_ops:
+            out += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
+            self.ool.append([label(l_eq), I("s_nop", 11)] + eq_ops + [I("s_branch", Label(l_back))])
         if jd > 0:
             out += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
+            self.ool.append([label(l_lt), I("s_nop", 11)] + [I("v_mov_b32", V(Y + 16 * g + r), ninf) for r in range(16)] +
+                            [I("s_branch", Label(l_back))])
         out += [label(l_back)]
-        ninf = V(V_NINF)
-        blk = [label(l_eq), I("s_nop", 11)]   # the chain of group 3 ended with the last MFMA of phase A
-        for r in range(16):
-            key = (r & 3) + 8 * (r >> 2)
-            blk += [I("v_cmp_lt_i32", VCC, V(V_IMH), key),
-                    I("v_cndmask_b32", V(Y + r), V(Y + r), ninf, VCC), I("v_cndmask_b32", V(Y + 48 + r), V(Y + 48 + r), ninf, VCC),
-                    I("v_mov_b32", V(Y + 16 + r), ninf)]
-        blk += [I("s_branch", Label(l_back))]
-        self.ool.append(blk)
-        if jd > 0:
-            blk = [label(l_lt), I("s_nop", 11)]
-            blk += [I("v_mov_b32", V(Y + r), ninf) for r in range(64)]
-            blk += [I("s_branch", Label(l_back))]
-            self.ool.append(blk)
         return out
 
-    def phase_b(self, t4, with_pv=True, with_start=True, init=False, with_kread=True, with_dma=True, steady=False,
-                save=False, pre=(), qload=None, mask=None, early=(), late=()):
-        """B(t), t4 = t & 3: P.V(t) from S[p]  ||  start-softmax(t+1) on S[1-p]  ||  K(t+2) reads from KB[(t+2) & 3]
-        ||  LDS-DMA V(t+3) -> VB[(t+3) & 3], K(t+4) -> KB[t4].
-        init: the tile started here is the first of a job (m := its row maximum, sums := 0, no decision)
-        save: this is the last tile of a job: its row sums and maximum are put aside for the epilogue
-        pre: instructions ahead of the phase (descriptor switches);  qload: the next job's Q loads, issued first"""
+    # ------------------------------------------------------------------ the two phases
+    def emit_phase(self, mfmas, gaps):
+        """gaps[k] = fillers behind MFMA k: (order, [insts]) with order 0 = LDS / DMA loads, 1 = exp2, 2 = the rest, 3 = last"""
+        out = []
+        for k, m in enumerate(mfmas):
+            out.append(m)
+            for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
+                out += ins
+        return out
+
+    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False):
+        """A(t), t4 = t & 3: QK^T(t+1) -> S[1-p]  ||  V(t) reads from VB[t % R]  ||  the late softmax operations of tile t (on S[p])
+        ||  the early ones of tile t+1 (on S[1-p])"""
         p = t4 & 1
         X, Y = SBUF[p], SBUF[1 - p]
+        abl = self.abl if steady else set()
+        mf = self.qk_mfmas(Y) if with_qk else []
+        gaps = {}
+        add = lambda k, order, ins: gaps.setdefault(min(max(int(k), 0), 31), []).append((order, ins))
+        if cur:
+            if "novread" not in abl:
+                for k, ins in enumerate(self.v_reads(t4 % self.R)):
+                    add(k, 0, [ins])
+            if "nofinish" not in abl:
+                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False):
+                    add(k, 1 if is_exp else 2, ins)
+        if nxt and "nostart" not in abl:
+            for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks):
+                add(k, 1 if is_exp else 2, ins)
+        if not mf:
+            return [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
+        return self.emit_phase(mf, gaps)
+
+    def pv_mfmas(self, X):
+        """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep) with P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s; behind each
+        k-step the row sums of its two P fragments on the matrix pipe: a 16x16x32 MFMA against the 0 / 1 operand V_ONES puts
+        the 16-key sum of the lane's own query into register 0 of V_LACC[qb] (fa2_mfma16h.hip, FA2_H_MSUM, has the lane maths)"""
+        out = []
+        mfma16 = "v_mfma_f32_16x16x32_" + self.dtype
+        for kstep in range(4):
+            kb, s = kstep >> 1, kstep & 1
+            for db in range(4):
+                for qb in range(2):
+                    pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
+                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), pf, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}"))
+            for qb in range(2):
+                pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
+                out.append(I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}"))
+        return out
+
+    def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
+                pre=(), early=(), late=(), masks=None):
+        """B(t), t4 = t & 3: P.V(t) and the row sums of P(t) from S[p]  ||  the middle softmax operations of tile t+1 (on S[1-p])
+        ||  K(t+2) reads from KB[(t+2) % R]  ||  LDS-DMA V(t+dv) -> VB[(t+dv) % R], K(t+dk) -> KB[(t+dk) % R].
+        pre: instructions ahead of the phase;  early: scalar work / register loads spread over the first gaps;
+        late: further DMA pieces (the next job's Q rows) behind this step's own"""
+        p = t4 & 1
+        X, Y = SBUF[p], SBUF[1 - p]
+        abl = self.abl if steady else set()
         mf = self.pv_mfmas(X) if with_pv else []
-        fill = []
+        NB = self.NB
+        gaps = {}
+        add = lambda k, order, ins: gaps.setdefault(min(max(int(k), 0), NB - 1), []).append((order, ins))
         head = list(pre)
         post = []
-        abl = self.abl if steady else set()
-        if "nokread" in abl:
-            with_kread = False
-        if "nostart" in abl:
-            with_start = False
-        if save:
-            for qb in range(2):
-                head += [I("v_add_f32", V(V_LSV[qb]), V(V_RS[qb][0]), V(V_RS[qb][1])), I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb]))]
-        if qload:
-            head += qload
-        if mask is not None:
-            head += self.mask_block(Y, *mask)
-        # scalar work and register loads that only have to precede this phase's DMA pieces: spread over the first gaps
-        ne = len(early)
-        for k, ins in enumerate(early):
-            fill.append((0.3 + 11.0 * k / max(ne, 1), [ins]))
-        if with_kread:
+        if with_kread and "nokread" not in abl:
             for k, ins in enumerate(self.k_reads((t4 + 2) % self.R)):
-                fill.append((0.2 + k * 0.75, [ins]))
+                add(self.b_kread_gap(k), 0, [ins])
         if with_dma:
             pieces = [self.dma_piece("v", j, (t4 + self.dv) % self.R) for j in range(4)] + \
                 [self.dma_piece("k", j, (t4 + self.dk) % self.R) for j in range(4)]
             for k, pc in enumerate(pieces):
                 if "nodma" in abl:
                     continue
-                fill.append((12.5 + 2.3 * k, pc) if not late else (6.0 + 1.2 * k, pc))
-            # further DMA pieces (the next job's Q rows) behind this step's own: the counted waits rely on that order
-            for k, pc in enumerate(late):
-                fill.append((16.0 + 15.5 * k / len(late), pc))
+                # (with further pieces behind them -- the seam's Q rows -- this step's own go first: the counted waits
+                # assume all eight are older than the sixteen)
+                g = self.b_dma_gap(k) if not late else (1, 3, 5, 7, 11, 13, 15, 17)[k]
+                # scalar set-up (soffset, M0) at the end of the previous gap, the load first in its own: the MFMA between
+                # them is the wait state the M0 write needs
+                setup, load = [x for x in pc if not x.op.startswith("buffer_load") and x.op != "s_nop"], [x for x in pc if x.op.startswith("buffer_load")]
+                add(g - 1, 3, setup)
+                add(g, 0, load if mf else [I("s_nop", 0)] + load)
             post += [I("s_add_u32", S_VDMA, S_VDMA, S_V64), I("s_add_u32", S_KDMA, S_KDMA, S_K64)]
-        if with_start:
-            t0, t1 = V(V_T[0]), V(V_T[1])
-            pos = 0.0
-            for ins in self.max_ops(Y):
-                if "nomax" not in abl:
-                    fill.append((pos, [ins]))
-                pos += 0.22
-            pos = max(pos, 7.1)
-            comb = []
-            for qb in range(2):
-                a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
-                comb += [I("v_max_f32", a, a, b)]
-            for qb in range(2):
-                a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
-                comb += [I("v_mov_b32", b, a)]
-            comb += [I("s_nop", 0)]
-            for qb in range(2):
-                a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
-                comb += [I("v_permlane32_swap_b32", a, b)]
-            for qb in range(2):
-                a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
-                comb += [I("v_max_f32", a, a, b)]          # full-row maximum (raw score units) in every lane
-            if init:
-                for qb in range(2):
-                    comb += [I("v_mul_f32", V(V_MC[qb]), S_C, V(V_MX[qb][0])),
-                             I("v_mov_b32", V(V_RS[qb][0]), 0), I("v_mov_b32", V(V_RS[qb][1]), 0)]
-                fill.append((pos, comb))
-            else:
-                l_fire, l_back = self.lab("fire"), self.lab("fire_back")
-                comb += [I("v_fma_f32", t0, V(V_MX[0][0]), S_C, -V(V_MC[0])), I("v_fma_f32", t1, V(V_MX[1][0]), S_C, -V(V_MC[1])),
-                         I("v_max_f32", t0, t0, t1), I("v_cmp_gt_f32", VCC, t0, S_THR), I("s_cbranch_vccnz", Label(l_fire)),
-                         label(l_back)]
-                fill.append((pos, comb))
-                # rare: raise the running maximum; O and the row sums are scaled at the END of this phase (after the
-                # P.V MFMAs of tile t, which were exponentiated against the old maximum)
-                blk = [label(l_fire)]
-                for qb in range(2):
-                    t2, t3 = V(V_T[2 + 2 * qb]), V(V_T[3 + 2 * qb])
-                    blk += [I("v_mul_f32", t2, S_C, V(V_MX[qb][0])), I("v_max_f32", t2, t2, V(V_MC[qb])),
-                            I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3)]
-                blk += [I("s_mov_b32", S_FLAG, 1), I("s_branch", Label(l_back))]
-                self.ool.append(blk)
-            # s' = s * c - m
-            pos += 0.6
-            nf = 64
-            span = 31.0 - pos
-            for k in range(nf):
-                g = k >> 4
-                qb = g >> 1
-                y = V(Y + k)
-                if "nofma" not in abl:
-                    fill.append((pos + k * span / nf, [I("v_fma_f32", y, y, S_C, -V(V_MC[qb]), tag=f"fma {k}")]))
-            # a few exp2 of the next finish phase ride here (phase A is the VALU-heavier one)
-            for k in range(self.nexp_b):
-                y = V(Y + k)
-                fill.append((pos + k * span / nf + 3.0, [I("v_exp_f32", y, y, tag=f"exp {k}")]))
+        ne = len(early)
+        for k, ins in enumerate(early):
+            add(1 + 12 * k // max(ne, 1), 2, [ins])   # done before this phase's own DMA pieces (gap 15 on) and the late ones
+        for k, pc in enumerate(late):   # whole units (they set M0 and a scratch offset): never between a piece's set-up and its load
+            add(20 + (NB - 21) * k // max(len(late), 1), 2, pc)
+        if nxt and "nostart" not in abl:
+            for k, ins, is_exp in self.tile_fill(Y, 32, 32 + NB, nxt_init, masks):
+                add(k, 1 if is_exp else 2, ins)
         if not mf:
-            body = [x for _, ins in sorted(fill, key=lambda f: f[0]) for x in ins]
+            body = [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
         else:
-            body = self.interleave(mf, fill)
+            body = self.emit_phase(mf, gaps)
         body = head + body + post
-        if with_start and not init:
-            # deferred rescale of O and the row sums (rare)
+        if nxt and not nxt_init or True:
+            # deferred rescale of O and the row sums by the factors the decisions of this step left (rare)
             l_rs, l_back = self.lab("rescale"), self.lab("rescale_back")
             body += [I("s_cmp_lg_u32", S_FLAG, 0), I("s_cbranch_scc1", Label(l_rs)), label(l_back)]
             blk = [label(l_rs), I("s_nop", 15)]
@@ -707,7 +813,8 @@ class Gen:
                     blk += [I("v_accvgpr_read_b32", tmp[k], regs[k]) for k in range(8)]
                     blk += [I("v_mul_f32", tmp[k], tmp[k], V(V_CO[qb])) for k in range(8)]
                     blk += [I("v_accvgpr_write_b32", regs[k], tmp[k]) for k in range(8)]
-                blk += [I("v_mul_f32", V(V_RS[qb][k]), V(V_RS[qb][k]), V(V_CO[qb])) for k in range(2)]
+                blk += [I("v_mul_f32", V(V_LACC[qb] + k), V(V_LACC[qb] + k), V(V_CO[qb])) for k in range(4)]
+                blk += [I("v_mov_b32", V(V_CO[qb]), 1.0)]
             blk += [I("s_mov_b32", S_FLAG, 0), I("s_nop", 3), I("s_branch", Label(l_back))]
             self.ool.append(blk)
         return body
@@ -719,21 +826,25 @@ class Gen:
             return [waitcnt(lgkmcnt=0), I("s_barrier")]
         if steady and "nobarrier" in self.abl:
             return [waitcnt(vmcnt=self.vm, lgkmcnt=0)]
-        return [waitcnt(vmcnt=self.vm, lgkmcnt=0, comment="the DMA pieces of two steps ago have landed; V fragments in"), I("s_barrier")]
+        return [waitcnt(vmcnt=self.vm, lgkmcnt=0, comment="the DMA pieces the next reads need have landed; V fragments in"), I("s_barrier")]
 
     def step(self, t4, a_pre=(), **kw):
         """one tile step, t4 = t & 3"""
+        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady")}
+        kb = {k: v for k, v in kw.items() if k in ("with_pv", "nxt", "nxt_init", "with_kread", "with_dma", "steady", "pre", "early", "late")}
+        if kw.get("masks") is not None:   # the masking tests of a score group sit in front of its first row-maximum operation
+            ka["masks"] = kw["masks"]
+            kb["masks"] = kw["masks"]
         out = [comment(f"---- step {t4}: phase A")]
         out += self.stamp_acc(2)
         out += list(a_pre)
         out += [waitcnt(lgkmcnt=0, comment="K fragments in")]
-        out += self.phase_a(t4, **{k: v for k, v in kw.items() if k in ("with_qk", "with_finish", "cinit", "steady")})
+        out += self.phase_a(t4, **ka)
         out += self.stamp_acc(0)
         out += self.sync_mid(kw.get("steady", False), kw.get("vm"))
         out += self.stamp_acc(1)
         out += [comment(f"---- step {t4}: phase B")]
-        out += self.phase_b(t4, **{k: v for k, v in kw.items()
-                                  if k in ("with_pv", "with_start", "init", "with_kread", "with_dma", "steady", "save", "pre", "qload", "mask", "early", "late")})
+        out += self.phase_b(t4, **kb)
         return out
 
     # ------------------------------------------------------------------ epilogue of the current job
@@ -746,13 +857,8 @@ class Gen:
         l = [t[0], t[3]]
         m2 = [t[1], t[4]]
         inv = [t[2], t[5]]
-        for qb in range(2):
-            e(I("v_mov_b32", l[qb], V(V_LSV[qb])), I("v_mov_b32", m2[qb], V(V_LSV[qb])))
-        e(I("s_nop", 1))
-        for qb in range(2):
-            e(I("v_permlane32_swap_b32", l[qb], m2[qb]))
-        for qb in range(2):
-            e(I("v_add_f32", l[qb], l[qb], m2[qb]))
+        for qb in range(2):   # register 0 of the row-sum accumulator is the lane's own complete row sum (both lane halves)
+            e(I("v_mov_b32", l[qb], V(V_LACC[qb])))
         for qb in range(2):
             e(I("v_rcp_f32", inv[qb], l[qb]), I("v_log_f32", m2[qb], l[qb]))
         e(I("s_nop", 0))
@@ -775,7 +881,7 @@ class Gen:
         rows = [V(SBUF[1] + 4 * k, 4) for k in range(8)]
         tset = [[V(SBUF[1] + 32 + 16 * sidx + k) for k in range(16)] for sidx in range(2)]
         aset = [[V(V_T[6]), V(V_T[7]), V(V_T[8]), V(V_T[9])], [V(V_MX[0][0]), V(V_MX[0][1]), V(V_MX[1][0]), V(V_MX[1][1])]]
-        addr2 = V(V_CO[0])
+        addr2 = V(V_LSV[0])   # (not V_CO: the rescale factors must stay 1.0 between firings)
 
         def weave(*lists):
             out, idx = [], [0] * len(lists)
@@ -822,8 +928,9 @@ class Gen:
                 e(I("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0], offen=1))
                 if k < 7:
                     e(I("s_add_u32", S_T[0], S_T[0], S_T[1]))
-        # O^T := 0 for the next job, on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
+        # O^T := 0 and row sums := 0 for the next job; O on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
         z = V(V_T[2], 4)
+        e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
         e([I("v_mov_b32", z.sub(k), 0) for k in range(4)], I("s_nop", 1))
         for qb in range(2):
             for db in range(4):
@@ -854,7 +961,7 @@ class Gen:
         e(self.stamp(1))
         e(self.q_reads(), self.k_reads(0))
         # step -1 (buffers as t4 = 3): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(2), K(3)
-        e(self.step(3, with_qk=True, with_finish=False, with_pv=False, init=True, mask=(0, (S_NT, 4)) if self.causal else None))
+        e(self.step(3, with_qk=True, cur=False, with_pv=False, nxt_init=True, masks=(0, (S_NT, 4)) if self.causal else None))
         e(self.stamp(2), self.stamp_flush(), self.stamp_acc(3))
         # ---- job loop
         e(label(l_job))
@@ -863,7 +970,7 @@ class Gen:
         e(label(l_loop))
         for t4 in range(4):
             # causal: the last steady body starts the job's first diagonal tile in its last phase B
-            e(self.step(t4, steady=True, mask=(0, (S_LOOP, 1)) if self.causal and t4 == 3 else None))
+            e(self.step(t4, steady=True, masks=(0, (S_LOOP, 1)) if self.causal and t4 == 3 else None))
         e(I("s_sub_u32", S_LOOP, S_LOOP, 1), I("s_cmp_lg_u32", S_LOOP, 0), I("s_cbranch_scc1", Label(l_loop)))
         e(label(l_seam))
         e(self.stamp(3), self.stamp_acc(2), self.stamp_flush())
@@ -877,7 +984,7 @@ class Gen:
             sk, sv = 4 - self.dk, 4 - self.dv      # seam step whose phase B streams the next job's first K / V tile
             qs_setup, qs_pieces = self.q_stage(S_NB, S_NHH, S_NQI)
             for st in range(4):
-                kw = dict(mask=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None)
+                kw = dict(masks=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None)
                 early, pre = [], []
                 if st == 0:
                     # the next job's Q rows start their way into the wave's LDS slice, BEHIND this step's K / V pieces; the
@@ -893,7 +1000,9 @@ class Gen:
                 if st == 2:
                     early += self.q_reads()      # slice -> a[128:191] (Q was last read by this step's phase A)
                 if st == 3:
-                    kw.update(init=True, save=True)
+                    # the job's last tile: its running maxima are put aside for the epilogue before the next job's first
+                    # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
+                    kw.update(nxt_init=True, a_pre=[I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)])
                 e(self.stamp(16 + st))
                 e(self.step(st, early=early, pre=pre, **kw))
         e(self.stamp(4))
@@ -906,6 +1015,8 @@ class Gen:
         e(label(l_end), waitcnt(vmcnt=0), self.stamp(7, real=True), self.stamp(9), I("s_endpgm"))
         for blk in self.ool:
             e(blk)
+        from .check import fix
+        self.prog, self.pads = fix(self.prog)
         return self.prog
 
     # ------------------------------------------------------------------ text

@@ -38,7 +38,7 @@ def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, n
     return b
 
 
-def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1, pow2=True):
+def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1, pow2=True, thr_override=None):
     """Q, K, V: float32 arrays (B, H, N, 128), rounded to dtype here.  Returns O (B,H,N,128) f32, L (B,H,N) f32."""
     B, H, N, D = Q.shape
     assert D == 128 and N % 256 == 0
@@ -58,6 +58,8 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     nwg = nwg or min(total, 256)
     sb, sh, sn = H * N * D * 2, N * D * 2, D * 2
     thr = 60.0 if dtype == "bf16" else 12.0
+    if thr_override is not None:
+        thr = thr_override
     ka = pack_kargs([bufs[k][0] for k in "QKVOL"], (sb, sh) * 4 + (H * N * 2, N * 2), (sn,) * 4, N, H, nq, total,
                     float(scale * LOG2E), thr, nunit, G, nbh, nwg, pow2=pow2)
     ka_arr = np.frombuffer(ka, np.uint8).copy()

@@ -108,7 +108,7 @@ def fmt_operand(o) -> str:
 
 
 # opcode classes (for the hazard checker and the issue-cost model)
-MFMA_OPS = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16"}
+MFMA_OPS = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16"}
 TRANS_OPS = {"v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"}
 DS_OPS = {"ds_read_b128", "ds_read_b64_tr_b16", "ds_write_b64", "ds_read_b64", "ds_write_b128", "ds_read_b32", "ds_write_b32"}
 VMEM_OPS = {"global_store_dwordx2", "buffer_load_dwordx4", "buffer_store_dwordx4", "buffer_store_short", "buffer_store_dword", "global_store_dword",

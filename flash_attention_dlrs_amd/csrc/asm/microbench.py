@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of instruction ISSUE cost beside v_mfma_f32_32x32x16_bf16 at one wave per SIMD (four waves per CU), the
+regime of the a64 kernel: each kernel runs  64 x [ 8 x ( MFMA ; n copies of instruction X ) ]  and writes the s_memtime
+cycles of the loop to the output buffer.  cycles per MFMA gap = total / 512; the slope over n is X's cost, the knee where
+it leaves 32 the number of free slots.   (diagnostic: scripts/probes/mb_run.hip loads the code object and prints the table)
+"""
+from __future__ import annotations
+
+import sys
+
+from .isa import A, I, Label, M0, S, V, VCC, label, waitcnt
+from .fa2_a64_gen import module_text
+
+
+class MB:
+    def __init__(self, name, fillers, agpr_c=True, chain=False):
+        self.name = name
+        self.prog = []
+        e = self.prog.append
+        # s[0:1] kernarg: {out ptr, src ptr}; s2 = workgroup id
+        e(I("s_load_dwordx4", S(4, 4), S(0, 2), 0))
+        e(I("v_and_b32", V(200), 63, V(0)))
+        e(I("v_lshlrev_b32", V(201), 4, V(200)))            # lane * 16: an LDS / buffer offset
+        e(I("v_lshrrev_b32", V(202), 6, V(0)))
+        e(I("s_nop", 1))
+        e(I("v_readfirstlane_b32", S(20), V(202)))           # wave
+        e(I("s_nop", 4))
+        for k in range(0, 192):
+            e(I("v_mov_b32", V(k), 0.5 if k % 3 else 1.0))
+        for k in range(0, 256, 1):
+            e(I("v_accvgpr_write_b32", A(k), 0))
+        e(I("v_mov_b32", V(203), 0.25))
+        e(waitcnt(lgkmcnt=0))
+        # buffer descriptor of the source buffer
+        e(I("s_mov_b32", S(8), S(6)))
+        e(I("s_and_b32", S(9), S(7), 0xFFFF))
+        e(I("s_mov_b32", S(10), 0x7FFFFFF0))
+        e(I("s_mov_b32", S(11), 0x00020000))
+        e(I("s_mov_b32", S(21), 1.4426950408889634))
+        e(I("s_lshl_b32", S(22), S(20), 12))                 # wave * 4096: LDS-DMA destination
+        e(I("s_mov_b32", S(23), 0))
+        e(I("s_barrier"))
+        e(I("s_memtime", S(12, 2)))
+        e(waitcnt(lgkmcnt=0))
+        e(I("s_mov_b32", S(16), 64))
+        lp = f".Lmb_{name}_loop"
+        e(label(lp))
+        for u in range(8):
+            if chain:
+                acc = A(0, 16) if agpr_c else V(0, 16)
+            else:
+                acc = A(16 * u, 16) if agpr_c else V(16 * (u % 4), 16)
+            e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
+            for f in fillers(u):
+                e(f)
+        e(I("s_sub_u32", S(16), S(16), 1))
+        e(I("s_cmp_lg_u32", S(16), 0))
+        e(I("s_cbranch_scc1", Label(lp)))
+        e(waitcnt(vmcnt=0, lgkmcnt=0))
+        e(I("s_memtime", S(14, 2)))
+        e(waitcnt(lgkmcnt=0))
+        e(I("s_sub_u32", S(14), S(14), S(12)))
+        # out[(wg * 4 + wave)] = cycles
+        e(I("s_lshl_b32", S(17), S(2), 2))
+        e(I("s_add_u32", S(17), S(17), S(20)))
+        e(I("s_lshl_b32", S(17), S(17), 2))
+        e(I("v_mov_b32", V(204), S(17)))
+        e(I("v_mov_b32", V(205), S(14)))
+        e(I("global_store_dword", V(204), V(205), S(4, 2)))
+        e(waitcnt(vmcnt=0))
+        e(I("s_endpgm"))
+
+    # reuse the kernel text / metadata emitters of the a64 generator (same descriptor: 512 registers, static LDS)
+    def text(self):
+        from .fa2_a64_gen import Gen
+        g = Gen.__new__(Gen)
+        g.name, g.prog = self.name, self.prog
+        return Gen.text(g)
+
+    def metadata(self):
+        from .fa2_a64_gen import Gen
+        g = Gen.__new__(Gen)
+        g.name = self.name
+        return Gen.metadata(g)
+
+
+def cases():
+    out = []
+    r = lambda u, k: 64 + 8 * u + k      # arch VGPR 64..127: never an MFMA operand here
+    EXP = lambda u, k: I("v_exp_f32", V(r(u, k)), V(r(u, k)))
+    ADD = lambda u, k: I("v_add_f32", V(120 + (k & 1)), V(120 + (k & 1)), V(r(u, k)))
+    FMA = lambda u, k: I("v_fma_f32", V(r(u, k)), V(r(u, k)), S(21), -V(203))
+    MX3 = lambda u, k: I("v_max3_f32", V(124 + (k & 3)), V(124 + (k & 3)), V(r(u, k)), V(r(u, (k + 1) % 8)))
+    CVT = lambda u, k: I("v_cvt_pk_bf16_f32", V(r(u, k)), V(r(u, k)), V(r(u, (k + 1) % 8)))
+    DSR = lambda u, k: I("ds_read_b128", V(64 + 4 * ((8 * u + k) % 8), 4), V(201), offset=1024 * ((8 * u + k) % 16))
+    TRR = lambda u, k: I("ds_read_b64_tr_b16", V(64 + 2 * ((8 * u + k) % 16), 2), V(201), offset=512 * ((8 * u + k) % 32))
+    SAL = lambda u, k: I("s_add_u32", S(23), S(23), 1)
+    PKA = lambda u, k: I("v_pk_add_f32", V(120, 2), V(120, 2), V(64 + 8 * u + 2 * (k % 4), 2))
+    def DMA3(u, k):
+        return I("buffer_load_dwordx4", V(201), S(8, 4), 0, offen=1, lds=1)
+    M0S = lambda u, k: I("s_add_u32", M0, S(22), 1024 * (u % 4))
+    pats = {
+        "none": [],
+        "t_eafc": [TRR, EXP, ADD, FMA, CVT], "e_t_afc": [EXP, TRR, ADD, FMA, CVT], "eafc_t": [EXP, ADD, FMA, CVT, TRR],
+        "t_e": [TRR, EXP], "e_t": [EXP, TRR], "tt_e": [TRR, TRR, EXP], "t_ea": [TRR, EXP, ADD], "t_eaa": [TRR, EXP, ADD, ADD],
+        "tt_afc": [TRR, TRR, ADD, FMA, CVT], "t_afcm": [TRR, ADD, FMA, CVT, MX3], "tt_aff": [TRR, TRR, ADD, FMA, FMA],
+        "d_aaff": [DSR, ADD, ADD, FMA, FMA], "dd_aff": [DSR, DSR, ADD, FMA, FMA], "d_e": [DSR, EXP], "d_eaa": [DSR, EXP, ADD, ADD],
+        "tt_aa": [TRR, TRR, ADD, ADD], "tt_a": [TRR, TRR, ADD], "tt": [TRR, TRR], "t_aaaa": [TRR, ADD, ADD, ADD, ADD],
+        "pk": [PKA], "pkpk": [PKA, PKA], "e_pkpk": [EXP, PKA, PKA], "pk4": [PKA] * 4,
+        "m_dma": [M0S, DMA3], "m_dma_e": [M0S, DMA3, EXP], "m_dma_eaa": [M0S, DMA3, EXP, ADD, ADD], "m_dma_aaf": [M0S, DMA3, ADD, ADD, FMA],
+        "e_aa_m_dma": [EXP, ADD, ADD, M0S, DMA3],
+    }
+    for nm, pat in pats.items():
+        out.append(MB(f"mb_{nm}", (lambda u, pat=pat: [f(u, k) for k, f in enumerate(pat)])))
+    # alternating gaps: even gaps carry the exps, odd gaps the plain VALU
+    def alt(u):
+        if u & 1:
+            return [ADD(u, 0), ADD(u, 1), FMA(u, 2), FMA(u, 3), ADD(u, 4), FMA(u, 5)]
+        return [EXP(u, 0), EXP(u, 1), ADD(u, 2), FMA(u, 3)]
+    out.append(MB("mb_alt_2e2v_6v", alt))
+    def alt2(u):
+        if u & 1:
+            return [ADD(u, 0), ADD(u, 1), FMA(u, 2), FMA(u, 3), ADD(u, 4), FMA(u, 5), CVT(u, 6)]
+        return [EXP(u, 0), EXP(u, 1), EXP(u, 2)]
+    out.append(MB("mb_alt_3e_7v", alt2))
+    return out
+
+
+def main(argv=None):
+    out = argv[0] if argv else "mb.s"
+    ks = cases()
+    for k in ks:
+        k.prog = [x for x in k.prog if x is not None]
+    with open(out, "w") as f:
+        f.write(module_text(ks))
+    with open(out + ".names", "w") as f:
+        f.write("\n".join(k.name for k in ks) + "\n")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

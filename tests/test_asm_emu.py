@@ -72,5 +72,15 @@ def test_emulated_kernel_job_stream_and_wave_order(oracle):
     _run(oracle, "bf16", True, 1, 3, 256, nwg=1, order=[2, 0, 3, 1], seed=1)
 
 
+def test_emulated_kernel_frequent_rescales_across_jobs(oracle):
+    # a low deferral threshold makes every rare path (firing, deferred rescale) run in every step, across job seams
+    rng = np.random.default_rng(4)
+    Q, K, V = (rng.standard_normal((1, 2, 512, 128)).astype(np.float32) for _ in range(3))
+    _, p = prog("bf16", True)
+    O, L, _ = harness.run(p, Q, K, V, dtype="bf16", causal=True, nwg=1, thr_override=8.0)
+    O_ref, _ = harness.reference(Q, K, V, dtype="bf16", causal=True)
+    assert not np.isnan(O).any() and np.abs(O - O_ref).max() <= O_TOL["bf16"]
+
+
 def test_emulated_kernel_rescale_path(oracle):
     _run(oracle, "bf16", False, 1, 1, 512, spike=True, seed=2)
