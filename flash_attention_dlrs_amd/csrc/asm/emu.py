@@ -341,6 +341,12 @@ class Workgroup:
             b = b - (1 << 32) if b & 0x80000000 else b
         w.scc = int(f(a, b))
 
+    def x_s_cmp_lg_u64(self, w, i):
+        w.scc = int(w.rd_s(i.ops[0]) != w.rd_s(i.ops[1]))
+
+    def x_s_bitcmp1_b32(self, w, i):
+        w.scc = int((w.rd_s(i.ops[0]) >> (w.rd_s(i.ops[1]) & 31)) & 1)
+
     def x_s_cmp_lt_u32(self, w, i):
         self._scmp(w, i, lambda a, b: a < b)
 

@@ -88,7 +88,7 @@ def V_F(kstep, db):
 # SGPRs.  s4..s47 hold the kernel arguments (loaded once).
 S_KARG = S(0, 2)
 S_WGID = S(2)
-S_FINAL = S(3)
+S_FINAL = S(75)
 S_Q, S_K, S_V, S_O, S_L = S(4, 2), S(6, 2), S(8, 2), S(10, 2), S(12, 2)
 S_QSB, S_QSH, S_KSB, S_KSH, S_VSB, S_VSH, S_OSB, S_OSH, S_LSB, S_LSH = (S(14 + 2 * k, 2) for k in range(10))
 S_QSN, S_KSN, S_VSN, S_OSN = S(34), S(35), S(36), S(37)
@@ -108,7 +108,8 @@ S_T = tuple(S(88 + k) for k in range(8))  # temporaries s88..s95 (S_T[0] even: u
 S_QROW = (S(96), S(97))          # first row of the wave's query block qb (current job)
 S_DBG = S(98, 2)
 S_KW, S_VW = S(100), S(101)      # 8 * wave * row stride: the wave's row base inside a tile
-S_LG, S_X1 = S(73), S(75)        # decode shifts: lgH | lgG << 8 | lg(G * nunit) << 16 | pow2-mode << 24;  spare
+S_LG = S(73)                     # decode shifts: lgH | lgG << 8 | lg(G * nunit) << 16 | pow2-mode << 24
+S_FIRE = (S(0, 2), S(2, 2))      # per query block: lanes whose row maximum passed the deferral threshold (s0..s3 are free after the set-up)
 S_X2 = S(82)
 
 # LDS map (bytes)
@@ -165,8 +166,9 @@ class Gen:
                 I("v_mov_b32", V(V_T[7]), 0), I("global_store_dwordx2", V(V_T[7]), v, S_DBG, offset=8 * slot)]
 
     def stamp_acc(self, k):
-        """diagnostic builds only: acc[k] += cycles since the previous stamp_acc"""
-        if not self.stamps:
+        """diagnostic builds only: acc[k] += cycles since the previous stamp_acc (its s_waitcnt drains the LDS queue as well: the
+        per-phase shares cost cycles of their own -- the "lite" kernels carry the job-level stamps only)"""
+        if not self.stamps or "lite" in self.abl:
             return []
         t = S(S_T[0].idx, 2)
         tmp = V(V_T[9])
@@ -519,7 +521,7 @@ class Gen:
     def tile_plan(self, init=False, lean=False):
         """placement of the per-tile softmax operations: returns [(tau, kind, payload)] sorted by tau.
         kinds: 'mx' (g, j)  'dec' (qb, part)  'f' e  'e' e  'cv' (g, j)"""
-        key = ("plan", init)
+        key = "plan"
         if key in self._cache:
             return self._cache[key]
         P = self.PERIOD
@@ -562,9 +564,11 @@ class Gen:
         t_dec = {}
         for qb in range(2):
             t = max(t_mx[2 * qb], t_mx[2 * qb + 1])
-            nparts = 3 if init else 4
-            for part in range(nparts):
-                t = place(t, (9, 5, 9, 9)[part], "dec", (qb, part)) + 1
+            # (the compare and the branch on it sit in different gaps: back to back the branch waits ~30 cycles for the mask.
+            # A job's first tile has no decision to take but keeps the slots: the loop body that finishes it is the one that
+            # finishes every other tile, so both placements must agree)
+            for part in range(5):
+                t = place(t, (9, 5, 9, 4, 2)[part], "dec", (qb, part)) + 1
             t_dec[qb] = t
         # s' = s * c - m, exp2, pack -- element order inside a group is the packing order
         for qb in range(2):
@@ -640,6 +644,10 @@ class Gen:
                 if init:
                     return [I("v_max_f32", a, a, b), I("v_mul_f32", V(V_MC[qb]), S_C, a)]
                 return [I("v_max_f32", a, a, b), I("v_fma_f32", d, a, S_C, -V(V_MC[qb]))]
+            if init:
+                return []
+            if part == 3:
+                return [I("v_cmp_gt_f32", S_FIRE[qb], d, S_THR)]
             l_fire, l_back = self.lab("fire"), self.lab("fire_back")
             # rare: raise this query block's running maximum now (every s' = s * c - m of the PREVIOUS tile has been formed:
             # plan order), remember the factor; O and the row sums are scaled at the end of the coming phase B
@@ -647,7 +655,7 @@ class Gen:
             self.ool.append([label(l_fire), I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
                              I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
                              I("s_mov_b32", S_FLAG, 1), I("s_branch", Label(l_back))])
-            return [I("v_cmp_gt_f32", VCC, d, S_THR), I("s_cbranch_vccnz", Label(l_fire)), label(l_back)]
+            return [I("s_cmp_lg_u64", S_FIRE[qb], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
         if kind == "f":
             e = payload
             y = V(Sb + e)
@@ -660,7 +668,7 @@ class Gen:
             return [I(self.cvt, V(Sb + 16 * g + j), V(Sb + 16 * g + 2 * j), V(Sb + 16 * g + 2 * j + 1), tag=f"cvt g{g} {j}")]
         raise KeyError(kind)
 
-    def tile_fill(self, Sb, lo, hi, init, masks=None):
+    def tile_fill(self, Sb, lo, hi, init, masks=None, abl=()):
         """[(gap - lo, [insts], is_exp)] of the tile's operations with lo <= tau < hi.  masks: causal (jd, cond) -> the masking
         tests of score group g go in front of its first row-maximum operation"""
         out = []
@@ -668,6 +676,8 @@ class Gen:
         for t, kind, payload in self.tile_plan(init):
             if not (lo <= t < hi):
                 continue
+            if ("no_" + kind) in abl or (kind == "dec" and payload[1] >= 3 and "no_fire" in abl):
+                continue   # timing-only ablations (diagnostic build)
             ins = self.tile_op(Sb, kind, payload, init)
             if masks is not None and kind == "mx" and payload[1] == 0 and payload[0] not in seen_mask:
                 seen_mask.add(payload[0])
@@ -729,10 +739,10 @@ class Gen:
                 for k, ins in enumerate(self.v_reads(t4 % self.R)):
                     add(k, 0, [ins])
             if "nofinish" not in abl:
-                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False):
+                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False, abl=abl):
                     add(k, 1 if is_exp else 2, ins)
         if nxt and "nostart" not in abl:
-            for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks):
+            for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks, abl=abl):
                 add(k, 1 if is_exp else 2, ins)
         if not mf:
             return [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
@@ -794,7 +804,7 @@ class Gen:
         for k, pc in enumerate(late):   # whole units (they set M0 and a scratch offset): never between a piece's set-up and its load
             add(20 + (NB - 21) * k // max(len(late), 1), 2, pc)
         if nxt and "nostart" not in abl:
-            for k, ins, is_exp in self.tile_fill(Y, 32, 32 + NB, nxt_init, masks):
+            for k, ins, is_exp in self.tile_fill(Y, 32, 32 + NB, nxt_init, masks, abl=abl):
                 add(k, 1 if is_exp else 2, ins)
         if not mf:
             body = [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
@@ -826,7 +836,12 @@ class Gen:
             return [waitcnt(lgkmcnt=0), I("s_barrier")]
         if steady and "nobarrier" in self.abl:
             return [waitcnt(vmcnt=self.vm, lgkmcnt=0)]
-        return [waitcnt(vmcnt=self.vm, lgkmcnt=0, comment="the DMA pieces the next reads need have landed; V fragments in"), I("s_barrier")]
+        out = [waitcnt(vmcnt=self.vm, lgkmcnt=0, comment="the DMA pieces the next reads need have landed; V fragments in"), I("s_barrier")]
+        if steady and "skew" in self.abl:   # experiment: wave w leaves the barrier 8 w cycles late
+            l1, l2 = self.lab("skew1"), self.lab("skew2")
+            out += [I("s_bitcmp1_b32", S_WAVE, 0), I("s_cbranch_scc0", Label(l1)), I("s_nop", 7), label(l1),
+                    I("s_bitcmp1_b32", S_WAVE, 1), I("s_cbranch_scc0", Label(l2)), I("s_nop", 15), label(l2)]
+        return out
 
     def step(self, t4, a_pre=(), **kw):
         """one tile step, t4 = t & 3"""
@@ -1043,9 +1058,13 @@ class Gen:
             f"    .wavefront_size: 64"])
 
 
-ABLATIONS = {"kreadv": ("kread_vgpr",), "novmwait": ("novmwait",), "nobarrier": ("nobarrier",), "nomax": ("nomax",), "nofma": ("nofma",),
+ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
              "nodma": ("nodma",), "nokread": ("nokread",), "nostart": ("nostart",), "nofinish": ("nofinish",),
-             "novread": ("novread",), "mfmaonly": ("nodma", "nokread", "nostart", "nofinish", "novread")}
+             "novread": ("novread",), "mfmaonly": ("nodma", "nokread", "nostart", "nofinish", "novread"),
+             "nomx": ("no_mx",), "nodec": ("no_dec",), "nofire": ("no_fire",), "nof": ("no_f",), "noe": ("no_e",), "nocv": ("no_cv",),
+             "nofecv": ("no_f", "no_e", "no_cv"), "nolds": ("nokread", "novread", "nodma"),
+             "nobar_nostart": ("nobarrier", "nostart"), "nobar_nolds": ("nobarrier", "nokread", "novread", "nodma"),
+             "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire")}
 
 
 def module_text(gens):
@@ -1073,8 +1092,11 @@ def main(argv=None):
                 return 1
             gens.append(g)
     if args.stamps:  # timing-only ablations ride in the diagnostic code object
-        for nm, abl in ABLATIONS.items():
-            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=abl)
+        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite", stamps=True, abl=("lite",))
+        g.build()
+        gens.append(g)
+        for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
+            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
             g.build()
             gens.append(g)
     with open(args.output, "w") as f:

@@ -187,7 +187,7 @@ class Inst:
             return d, [("scc", 0)]
         if op.startswith("s_cbranch_vcc"):
             return d, VCC.regs()
-        if op.startswith("s_cmp_"):
+        if op.startswith("s_cmp_") or op.startswith("s_bitcmp"):
             return [("scc", 0)], R(o[0]) + R(o[1])
         if op.startswith("s_load_") or op in ("s_memtime", "s_memrealtime"):
             return R(o[0]), (R(o[1]) if len(o) > 1 else [])
