@@ -7,9 +7,12 @@ and write the CSV the reference's plotting script reads:
     bench_out/fused-attention-B{B}-H{H}-d{d}-fwd-{dtype}.csv      (src/bench.py:47, src/plot_bench_results.py:41-57)
 
 with an `N` column and one column of mean milliseconds per provider display name.  Providers: this
-repository's kernel (in the column the reference gives its own "indet" Triton kernel), torch SDPA default /
-math on the GPU.  The competitor providers of the reference (flash-attn CUDA wheel, OpenAI tutorial) do not
-exist on ROCm and are omitted (NaN columns would break nothing in the plot script, they are simply absent).
+repository's kernel, and the reference's torch providers under the reference's own display names
+(src/bench.py:38-41,76-85): "Torch FA-2" (SDPBackend.FLASH_ATTENTION), "Torch xFormers"
+(SDPBackend.EFFICIENT_ATTENTION), "Torch Math" (SDPBackend.MATH), plus torch's default dispatch.  A backend
+this torch build cannot run for the shape gives NaN, as an out-of-memory does in the reference
+(src/bench.py:100-110).  The competitor providers of the reference that are CUDA wheels (flash-attn, the
+vendored OpenAI tutorial) do not exist on ROCm and are omitted.
 A second file `...-tflops.csv` carries the same sweep as TFLOP/s (4*B*H*N^2*d / t; backward: 2.5 x that,
 the convention of the vendored tutorial, src/flash_attention_openai_tutorial.py:630-635).  Mode "bwd" times
 `O.backward(dO, retain_graph=True)` exactly as the reference does (src/bench.py:93-96).
@@ -62,14 +65,17 @@ def do_bench(fn, warmup_ms=25, rep_ms=100):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-max-log", type=int, default=N_MAX_log)
-    ap.add_argument("--providers", default="hip,torch-sdpa,torch-math")
+    ap.add_argument("--providers", default="hip,torch-sdpa,torch-fa,torch-xformers,torch-math")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "bwd"])
+    ap.add_argument("--out-dir", default=BENCH_DIR)
     args = ap.parse_args()
     torch.manual_seed(42)  # src/bench.py:26
     gpu = torch.device("cuda")
     dtype_str = str(DTYPE).split(".")[1]
     names = {"hip": f"MI355X HIP FA-2 [{dtype_str.upper()}]", "torch-sdpa": f"Torch SDPA default [{dtype_str.upper()}]",
+             "torch-fa": f"Torch FA-2 [{dtype_str.upper()}]", "torch-xformers": f"Torch xFormers [{dtype_str.upper()}]",
              "torch-math": f"Torch Math [{dtype_str.upper()}]"}
+    backends = {"torch-fa": "FLASH_ATTENTION", "torch-xformers": "EFFICIENT_ATTENTION", "torch-math": "MATH"}
     providers = args.providers.split(",")
     rows = []
     for N in [2 ** i for i in range(N_MIN_log, args.n_max_log + 1)]:
@@ -84,8 +90,8 @@ def main():
             elif p == "torch-sdpa":
                 fn = lambda: torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1)
             else:
-                def fn():
-                    with torch.nn.attention.sdpa_kernel(torch.nn.attention.SDPBackend.MATH):
+                def fn(backend=getattr(torch.nn.attention.SDPBackend, backends[p])):
+                    with torch.nn.attention.sdpa_kernel(backend):
                         return torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=1)
             try:
                 if p == "torch-math" and N > (4096 if args.mode == "bwd" else 8192):
@@ -102,8 +108,8 @@ def main():
             row[names[p]] = ms
             print(f"Benchmarking {args.mode} (N={N}, H={H}, B={B}, d={d}) for {p} ... {ms:.4f} ms", flush=True)
         rows.append(row)
-    os.makedirs(BENCH_DIR, exist_ok=True)
-    base = os.path.join(BENCH_DIR, f"fused-attention-B{B}-H{H}-d{d}-{args.mode}-{dtype_str}")
+    os.makedirs(args.out_dir, exist_ok=True)
+    base = os.path.join(args.out_dir, f"fused-attention-B{B}-H{H}-d{d}-{args.mode}-{dtype_str}")
     cols = ["N"] + [names[p] for p in providers]
     with open(base + ".csv", "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=cols)

@@ -31,10 +31,11 @@ int validate(const Fa2Problem &p) {
         fa2_set_error("unknown dtype enum %d", p.dtype);
         return FA2_ERR_UNSUPPORTED;
     }
-    // The reference's host glue pads d to max(next_pow2(d), 16) before launching
-    // (src/flash_attention_torch.py:38); the kernel boundary therefore only ever sees such d.
-    if (!is_pow2(p.d) || p.d < 16 || p.d > 512) {
-        fa2_set_error("d=%d must be a power of two in [16, 512] (pad on the host as the reference does)", p.d);
+    // The reference's host glue pads d to max(next_pow2(d), 16) before launching (src/flash_attention_torch.py:38); here
+    // any head size goes to the kernels as it is: the MFMA kernels zero-fill the missing columns
+    // on load, the generic kernel loops to d.
+    if (p.d < 1 || p.d > 512) {
+        fa2_set_error("d=%d must be in [1, 512]", p.d);
         return FA2_ERR_UNSUPPORTED;
     }
     for (int k = 0; k < 4; ++k)
@@ -119,6 +120,10 @@ int pick_variant(const Fa2Problem &p) {
         return wg256 >= 160 && even ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
     }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;
+    // 16-bit head sizes other than 64 / 128 (multiples of 8): the first MFMA kernel with the missing columns zero-filled
+    // on load; 8 waves when there are enough 256-row tiles for the 256 CUs
+    if (fa2_mfma16_supports_dp(p))
+        return (long long)((p.N + 255) / 256) * p.B * p.H >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
     return FA2_VARIANT_GENERIC;
 }
 

@@ -39,6 +39,7 @@ bool fa2_a64_supports(const Fa2Problem &p);
 bool fa2_mfma8_supports(const Fa2Problem &p);
 bool fa2_mfma8x_supports(const Fa2Problem &p);
 bool fa2_mfma16_supports(const Fa2Problem &p);
+bool fa2_mfma16_supports_dp(const Fa2Problem &p);   // + the other multiples of 8 up to 128 (fa2_mfma16.hip only)
 bool fa2_mfma32_supports(const Fa2Problem &p);
 
 void fa2_set_error(const char *fmt, ...);

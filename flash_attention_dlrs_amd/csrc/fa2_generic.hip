@@ -2,8 +2,8 @@
 //
 // Covers everything the reference's host glue can hand to its Triton kernel
 // (src/flash_attention_torch.py:24-47): every dtype of convert_triton_dtype (:7-18) plus bf16 / e4m3,
-// arbitrary element strides on all four axes (src/flash_attention_kernels.py:45-79), d = 2^k in
-// [16, 512] (the padded head size, torch.py:38), and -- beyond the reference, whose tiles need
+// arbitrary element strides on all four axes (src/flash_attention_kernels.py:45-79), any d in
+// [1, 512] (the reference pads to a power of two on the host, torch.py:38), and -- beyond the reference, whose tiles need
 // N % 16 == 0 (src/autotune_configs.py:184-187) -- any N >= 1.  It is the fallback behind the MFMA
 // kernels (fa2_mfma16.hip, fa2_mfma32.hip), not the fast path: contractions run on the VALU.
 //
@@ -172,13 +172,15 @@ __global__ __launch_bounds__(kWaves * 64) void fa2_fwd_generic_kernel(const Gene
 template <class E> int launch_e(const Fa2Problem &p, const GenericArgs &a) {
     const dim3 grid((p.N + kBr - 1) / kBr, p.B, p.H), block(kWaves * 64);
     const size_t smem = sizeof(typename E::acc_t) * ((size_t)kBr * p.d + (size_t)kWaves * kRowsPerWave * kBc);
+    // output columns per lane: ceil(d / 64) rounded up to the next instantiation (columns >= d are skipped in the kernel)
     const int dpl = (p.d + 63) / 64;
-    switch (dpl) {
-    case 1: hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 1>), grid, block, smem, p.stream, a); break;
-    case 2: hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 2>), grid, block, smem, p.stream, a); break;
-    case 4: hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 4>), grid, block, smem, p.stream, a); break;
-    case 8: hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 8>), grid, block, smem, p.stream, a); break;
-    default: fa2_set_error("generic kernel: d=%d not a power of two in [16,512]", p.d); return FA2_ERR_UNSUPPORTED;
+    if (dpl <= 1) hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 1>), grid, block, smem, p.stream, a);
+    else if (dpl <= 2) hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 2>), grid, block, smem, p.stream, a);
+    else if (dpl <= 4) hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 4>), grid, block, smem, p.stream, a);
+    else if (dpl <= 8) hipLaunchKernelGGL((fa2_fwd_generic_kernel<E, 8>), grid, block, smem, p.stream, a);
+    else {
+        fa2_set_error("generic kernel: d=%d not in [1, 512]", p.d);
+        return FA2_ERR_UNSUPPORTED;
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -55,6 +55,7 @@ struct Mfma16Args {
     int64_t ls[2];                       // L strides in elements
     int B, H, N;
     float c_log2e;  // scale * log2(e) > 0
+    int dbytes;     // row bytes of the head size the caller passed (<= 2 D): the DP kernels zero-fill the rest
 };
 
 // Byte offset of 16-byte chunk `ch` of row `row` inside one [64][D] 16-bit tile.
@@ -68,7 +69,10 @@ template <int D> __device__ __forceinline__ int lds_off(int row, int ch) {
     else return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
 }
 
-template <typename T, int D, int NW, bool CAUSAL>
+// DP: the head size is not D itself (any multiple of 8 below it -- SURVEY section 8 row f2): 16-byte chunks at or past
+// a.dbytes are zero-filled on their way into the fragments / LDS and never stored, instead of the host padding Q, K, V
+// (reference torch.py:38-47).  Zero columns add nothing to Q.K^T and yield the zero columns of O the reference slices away.
+template <typename T, int D, int NW, bool CAUSAL, bool DP>
 __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16_kernel(const Mfma16Args a) {
     using M = Mma<T>;
     using frag = typename M::frag;
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16_kernel(const Mfma16
         row = row < N ? row : N - 1;
         const char *qp = Qp + (int64_t)row * a.qs[2] + h * 16;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(frag, *(const u32x4 *)(qp + ks * 32));
+        for (int ks = 0; ks < KS; ++ks)
+            qf[ks] = __builtin_bit_cast(frag, (!DP || h * 16 + ks * 32 < a.dbytes) ? *(const u32x4 *)(qp + ks * 32) : u32x4{0, 0, 0, 0});
     }
 
     // ---- staging map: thread handles chunk (row = it*RPI + tid/CPR, ch = tid%CPR) of each tile.
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16_kernel(const Mfma16
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
             const int key = t * BC + it * RPI + st_row;
-            const bool ok = key < N;
+            const bool ok = key < N && (!DP || st_ch * 16 < a.dbytes);
             const int64_t ro = (int64_t)(t * BC + it * RPI);
             kreg[it] = ok ? *(const u32x4 *)(kg + ro * a.ks[2]) : u32x4{0, 0, 0, 0};
             vreg[it] = ok ? *(const u32x4 *)(vg + ro * a.vs[2]) : u32x4{0, 0, 0, 0};
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa2_fwd_mfma16_kernel(const Mfma16
                 Tx4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (T)(o[db][4 * g + j] * inv);
-                *(u32x2 *)(op + db * 64 + g * 16) = __builtin_bit_cast(u32x2, v);
+                if (!DP || h * 8 + db * 64 + g * 16 < a.dbytes) *(u32x2 *)(op + db * 64 + g * 16) = __builtin_bit_cast(u32x2, v);
             }
         if (h == 0) {
             T *lp = (T *)a.L + b * a.ls[0] + hh * a.ls[1] + qrow;
@@ -290,10 +295,15 @@ template <typename T, int D, int NW> int launch_t(const Fa2Problem &p, const Mfm
     }
     const dim3 grid((unsigned)nblk), block(NW * 64);
     const size_t smem = 4 * 64 * D * 2;
-    if (p.causal)
-        hipLaunchKernelGGL((fa2_fwd_mfma16_kernel<T, D, NW, true>), grid, block, smem, p.stream, a);
+    if (p.d != D) {
+        if (p.causal)
+            hipLaunchKernelGGL((fa2_fwd_mfma16_kernel<T, D, NW, true, true>), grid, block, smem, p.stream, a);
+        else
+            hipLaunchKernelGGL((fa2_fwd_mfma16_kernel<T, D, NW, false, true>), grid, block, smem, p.stream, a);
+    } else if (p.causal)
+        hipLaunchKernelGGL((fa2_fwd_mfma16_kernel<T, D, NW, true, false>), grid, block, smem, p.stream, a);
     else
-        hipLaunchKernelGGL((fa2_fwd_mfma16_kernel<T, D, NW, false>), grid, block, smem, p.stream, a);
+        hipLaunchKernelGGL((fa2_fwd_mfma16_kernel<T, D, NW, false, false>), grid, block, smem, p.stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fa2_set_error("mfma16 kernel launch failed: %s", hipGetErrorString(e));
@@ -303,7 +313,7 @@ template <typename T, int D, int NW> int launch_t(const Fa2Problem &p, const Mfm
 }
 
 template <typename T> int launch_d(const Fa2Problem &p, const Mfma16Args &a, int waves) {
-    if (p.d == 128) return waves == 8 ? launch_t<T, 128, 8>(p, a) : launch_t<T, 128, 4>(p, a);
+    if (p.d > 64) return waves == 8 ? launch_t<T, 128, 8>(p, a) : launch_t<T, 128, 4>(p, a);
     return waves == 8 ? launch_t<T, 64, 8>(p, a) : launch_t<T, 64, 4>(p, a);
 }
 
@@ -311,9 +321,10 @@ bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-bool fa2_mfma16_supports(const Fa2Problem &p) {
+// what this file's kernel takes: d = 64 and 128 natively, the other multiples of 8 up to 128 predicated (DP)
+bool fa2_mfma16_supports_dp(const Fa2Problem &p) {
     if (p.dtype != FA2_DTYPE_F16 && p.dtype != FA2_DTYPE_BF16) return false;
-    if (p.d != 64 && p.d != 128) return false;
+    if (p.d < 8 || p.d > 128 || (p.d & 7)) return false;
     if (!(p.scale > 0.0f) || !(p.scale < INFINITY)) return false;
     if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
     // 16-byte vector loads of Q/K/V rows, 8-byte stores of O: every row start must stay aligned.
@@ -324,9 +335,12 @@ bool fa2_mfma16_supports(const Fa2Problem &p) {
     return true;
 }
 
+// the common precondition of the 16-bit MFMA kernels (mfma16d / 16h / 16k / a64 add their own)
+bool fa2_mfma16_supports(const Fa2Problem &p) { return (p.d == 64 || p.d == 128) && fa2_mfma16_supports_dp(p); }
+
 int fa2_launch_mfma16(const Fa2Problem &p, int waves) {
-    if (!fa2_mfma16_supports(p)) {
-        fa2_set_error("mfma16 kernel: needs f16/bf16, d in {64,128}, unit d-stride, 16-byte aligned rows, scale > 0");
+    if (!fa2_mfma16_supports_dp(p)) {
+        fa2_set_error("mfma16 kernel: needs f16/bf16, d a multiple of 8 up to 128, unit d-stride, 16-byte aligned rows, scale > 0");
         return FA2_ERR_UNSUPPORTED;
     }
     Mfma16Args a;
@@ -338,5 +352,6 @@ int fa2_launch_mfma16(const Fa2Problem &p, int waves) {
     a.ls[0] = p.ls[0]; a.ls[1] = p.ls[1];
     a.B = p.B; a.H = p.H; a.N = p.N;
     a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
+    a.dbytes = p.d * 2;
     return p.dtype == FA2_DTYPE_BF16 ? launch_d<__bf16>(p, a, waves) : launch_d<_Float16>(p, a, waves);
 }

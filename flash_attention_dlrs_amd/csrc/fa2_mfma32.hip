@@ -31,12 +31,15 @@ struct Mfma32Args {
     int64_t ls[2];                       // elements
     int B, H, N;
     float c_log2e;
+    int dbytes;  // row bytes of the head size the caller passed (<= 4 D): the DP kernels zero-fill the rest
 };
 
 // 16-byte chunk `ch` of row `row` in a [32][D] fp32 tile: chunk ^= row & 15 (low four chunk bits).
 template <int D> __device__ __forceinline__ int lds_off32(int row, int ch) { return row * (D * 4) + ((ch ^ (row & 15)) << 4); }
 
-template <int D, bool CAUSAL>
+// DP: the head size is a multiple of 4 below D (e.g. the reference's d = 40 and d = 8 padding
+// cases, torch.py:38-47): 16-byte chunks at or past a.dbytes are zero-filled on load and never stored -- no host padding.
+template <int D, bool CAUSAL, bool DP>
 // d = 128 needs Q (64) + O (64) + S (16) + staging (32) + fragments > 256 registers: one workgroup per CU there
 // (with two, 61 registers spilled and Q was re-read from scratch every tile: 40 % of the fp32 MFMA peak).
 __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel(const Mfma32Args a) {
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel
         row = row < N ? row : N - 1;
         const char *qp = Qp + (int64_t)row * a.qs[2] + h * 16;
 #pragma unroll
-        for (int cidx = 0; cidx < NC; ++cidx) qf[cidx] = *(const f32x4 *)(qp + cidx * 32);
+        for (int cidx = 0; cidx < NC; ++cidx)
+            qf[cidx] = (!DP || h * 16 + cidx * 32 < a.dbytes) ? *(const f32x4 *)(qp + cidx * 32) : f32x4{0, 0, 0, 0};
     }
 
     const int st_row = tid / CPR, st_ch = tid % CPR;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
             const int key = t * BC + it * RPI + st_row;
-            const bool ok = key < N;
+            const bool ok = key < N && (!DP || st_ch * 16 < a.dbytes);
             const int64_t ro = (int64_t)(t * BC + it * RPI);
             kreg[it] = ok ? *(const f32x4 *)(kg + ro * a.ks[2]) : f32x4{0, 0, 0, 0};
             vreg[it] = ok ? *(const f32x4 *)(vg + ro * a.vs[2]) : f32x4{0, 0, 0, 0};
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void fa2_fwd_mfma32_kernel
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = o[db][4 * g + j] / l;  // :105
-                *(f32x4 *)(op + db * 128 + g * 32) = v;
+                if (!DP || h * 16 + db * 128 + g * 32 < a.dbytes) *(f32x4 *)(op + db * 128 + g * 32) = v;
             }
         if (h == 0) {
             float *lp = (float *)a.L + b * a.ls[0] + hh * a.ls[1] + qrow;
@@ -237,10 +241,15 @@ template <int D> int launch_d(const Fa2Problem &p, const Mfma32Args &a) {
     }
     const dim3 grid((unsigned)nblk), block(256);
     const size_t smem = 4 * 32 * D * 4;
-    if (p.causal)
-        hipLaunchKernelGGL((fa2_fwd_mfma32_kernel<D, true>), grid, block, smem, p.stream, a);
+    if (p.d != D) {
+        if (p.causal)
+            hipLaunchKernelGGL((fa2_fwd_mfma32_kernel<D, true, true>), grid, block, smem, p.stream, a);
+        else
+            hipLaunchKernelGGL((fa2_fwd_mfma32_kernel<D, false, true>), grid, block, smem, p.stream, a);
+    } else if (p.causal)
+        hipLaunchKernelGGL((fa2_fwd_mfma32_kernel<D, true, false>), grid, block, smem, p.stream, a);
     else
-        hipLaunchKernelGGL((fa2_fwd_mfma32_kernel<D, false>), grid, block, smem, p.stream, a);
+        hipLaunchKernelGGL((fa2_fwd_mfma32_kernel<D, false, false>), grid, block, smem, p.stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fa2_set_error("mfma32 kernel launch failed: %s", hipGetErrorString(e));
@@ -253,7 +262,7 @@ template <int D> int launch_d(const Fa2Problem &p, const Mfma32Args &a) {
 
 bool fa2_mfma32_supports(const Fa2Problem &p) {
     if (p.dtype != FA2_DTYPE_F32) return false;
-    if (p.d != 64 && p.d != 128) return false;
+    if (p.d < 4 || p.d > 128 || (p.d & 3)) return false;   // 64 and 128 natively, the other multiples of 4 predicated (DP)
     if (!(p.scale > 0.0f) || !(p.scale < INFINITY)) return false;
     if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
     for (int k = 0; k < 3; ++k)
@@ -265,7 +274,7 @@ bool fa2_mfma32_supports(const Fa2Problem &p) {
 
 int fa2_launch_mfma32(const Fa2Problem &p) {
     if (!fa2_mfma32_supports(p)) {
-        fa2_set_error("mfma32 kernel: needs f32, d in {64,128}, unit d-stride, 16-byte aligned rows, scale > 0");
+        fa2_set_error("mfma32 kernel: needs f32, d a multiple of 4 up to 128, unit d-stride, 16-byte aligned rows, scale > 0");
         return FA2_ERR_UNSUPPORTED;
     }
     Mfma32Args a;
@@ -277,5 +286,6 @@ int fa2_launch_mfma32(const Fa2Problem &p) {
     a.ls[0] = p.ls[0]; a.ls[1] = p.ls[1];
     a.B = p.B; a.H = p.H; a.N = p.N;
     a.c_log2e = (float)((double)p.scale * FA2_LOG2E);
-    return p.d == 128 ? launch_d<128>(p, a) : launch_d<64>(p, a);
+    a.dbytes = p.d * 4;
+    return p.d > 64 ? launch_d<128>(p, a) : launch_d<64>(p, a);
 }

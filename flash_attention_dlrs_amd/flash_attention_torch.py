@@ -72,11 +72,12 @@ def _forward_impl(ctx, Q, K, V, causal, scale):
     B, H, N, d = Q.shape
     dtype = convert_triton_dtype(Q.dtype)
 
-    # Support for non-power-of-2 d or d < 16 (reference torch.py:38)
+    # Non-power-of-2 d or d < 16: the reference pads Q, K, V on the host (torch.py:38-47) and returns the O[..., :d] view
+    # of a padded O.  The forward kernels take any d (the MFMA kernels zero-fill the missing
+    # columns on load, the generic kernel loops to d): no copies here, O comes back with exactly d columns.  Only the
+    # backward still wants a power of two and pads what it was handed (_backward_impl).
     d_proper = max(next_power_of_2(d), MIN_TENSOR_SIZE)
     padded = d_proper != d
-    if padded:
-        Q, K, V = (pad_last_dim(t, d_proper) for t in (Q, K, V))
 
     # O inherits Q's strides, L is (B, H, N, 1) in the input dtype (reference torch.py:50-51)
     O = torch.empty_like(Q)
@@ -93,7 +94,7 @@ def _forward_impl(ctx, Q, K, V, causal, scale):
     ctx.d_orig = d
     ctx.causal = bool(causal)
     ctx.scale = float(scale)
-    return O[:, :, :, 0:d] if padded else O
+    return O
 
 
 def attention_backward_recompute(Q, K, V, O, dO, L, causal=False, scale=1.0):
@@ -138,8 +139,8 @@ def _backward_impl(ctx, dO):
     Q, K, V, O, L = ctx.saved_tensors
     if Q.dtype != dO.dtype:
         raise ValueError("dO must have same dtype as inputs")
-    if ctx.padded:
-        dO = pad_last_dim(dO, ctx.d_used)
+    if ctx.padded:   # (reference torch.py:91-100 pads in its backward as well)
+        Q, K, V, O, dO = (pad_last_dim(t, ctx.d_used) for t in (Q, K, V, O, dO))
     dQ, dK, dV = backward_native(Q, K, V, O, dO, L, ctx.causal, ctx.scale)
     if ctx.padded:
         d = ctx.d_orig

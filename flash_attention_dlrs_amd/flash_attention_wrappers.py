@@ -19,14 +19,11 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
 
     B, H, N, d = Q.shape
 
-    # The reference pads to next_pow2(d) only (wrappers.py:27) and then breaks Triton's 16-minimum
-    # for d < 16; both of our surfaces pad to max(next_pow2(d), 16) like torch.py:38.
-    d_pow = max(next_power_of_2(d), MIN_TENSOR_SIZE)
-    if d_pow != d:
-        Q, K, V = (pad_last_dim(t, d_pow) for t in (Q, K, V))
+    # The reference pads Q, K, V to next_pow2(d) here (wrappers.py:27-34) and slices O afterwards; the kernels take any d
+    # (SURVEY section 8 row f2), so nothing is copied and O has exactly d columns.
 
     # Always-contiguous outputs (reference wrappers.py:37-38)
-    O = torch.empty(B, H, N, d_pow, dtype=Q.dtype, device=dev)
+    O = torch.empty(B, H, N, d, dtype=Q.dtype, device=dev)
     L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=dev)
 
     dtype = convert_triton_dtype(Q.dtype)
@@ -38,14 +35,14 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
         if v != _lib.VARIANT_AUTO:
             try:
                 _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
-                return (O if d_pow == d else O[:, :, :, 0:d]), L
+                return O, L
             except TypeError:
                 # the tuned variant cannot run THIS problem (strides, alignment, N * stride >= 2 GiB: the tuner's key does
                 # not see them): the static table can, it falls back to the kernels that take any layout
                 v = _lib.VARIANT_AUTO
     _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
 
-    return (O if d_pow == d else O[:, :, :, 0:d]), L
+    return O, L
 
 
 def flash_attention_backward(Q, K, V, O, dO, L, dev, deterministic=False, *, causal=False, scale=1.0, variant="auto"):

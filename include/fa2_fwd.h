@@ -40,18 +40,20 @@ extern "C" {
  * flash_attention_torch.py:24-32, :18). */
 #define FA2_OK 0
 #define FA2_ERR_BAD_ARG (-1)     /* null pointer, non-positive size, misaligned/negative stride  */
-#define FA2_ERR_UNSUPPORTED (-2) /* dtype enum unknown, or d not a power of two in [16, 512]     */
+#define FA2_ERR_UNSUPPORTED (-2) /* dtype enum unknown, d outside [1, 512], or a variant that cannot run the problem */
 #define FA2_ERR_BAD_N (-3)       /* N < 1                                                        */
 #define FA2_ERR_LAUNCH (-4)      /* HIP reported an error at launch                              */
 
 /* Kernel variants (fa2_fwd_variant / fa2_query_tile).  AUTO = the static gfx950 tile table that
  * replaces the reference's run-time autotuner (src/autotune_configs.py:24-201, kernels.py:11-15). */
 #define FA2_VARIANT_AUTO 0
-#define FA2_VARIANT_GENERIC 1 /* any dtype, any strides, d = 2^k in [16,512], any N; FMA on VALU  */
-#define FA2_VARIANT_MFMA16 2  /* f16/bf16, d in {64,128}, unit d-stride; 4 waves x 32 rows (the fallback when N * row     */
-                              /* stride does not fit 32-bit buffer offsets)                                           */
+#define FA2_VARIANT_GENERIC 1 /* any dtype, any strides, any d in [1,512], any N; FMA on VALU     */
+#define FA2_VARIANT_MFMA16 2  /* f16/bf16, unit d-stride; 4 waves x 32 rows.  d = 64 / 128, and every other multiple of 8  */
+                              /* up to 128 with the missing columns zero-filled on load (no host padding: the        */
+                              /* reference pads Q, K, V to a power of two, torch.py:38-47).  Also the fallback when  */
+                              /* N * row stride does not fit 32-bit buffer offsets                                    */
 #define FA2_VARIANT_MFMA16_W8 3 /* same, 8 waves x 32 rows (256-row Q tile)                        */
-#define FA2_VARIANT_MFMA32 4  /* f32 via v_mfma_f32_32x32x2_f32, d in {64,128}                     */
+#define FA2_VARIANT_MFMA32 4  /* f32 via v_mfma_f32_32x32x2_f32; d = 64 / 128, other multiples of 4 up to 128 zero-filled on load */
 #define FA2_VARIANT_MFMA16D 8 /* f16/bf16 software-pipelined (32-key blocks), LDS-DMA staging (buffer_load ... lds), 8 waves x 32 rows */
 #define FA2_VARIANT_MFMA16D_W4 9 /* same, 4 waves x 32 rows                                          */
 #define FA2_VARIANT_MFMA16H 14 /* MFMA16D with a persistent grid, next-job prefetch and a hand-ordered steady loop; 8 waves */

@@ -150,6 +150,97 @@ int fa2_oracle_fwd(const float *Q, const float *K, const float *V, float *O, flo
 }
 
 /*
+ * The same algorithm with the two liberties the gfx950 MFMA kernels take, made explicit so that those kernels can be
+ * compared ELEMENT-WISE (tests/test_a64_parity.py, tests/test_fwd_parity.py fp8) instead of through a tolerance:
+ *
+ *   deferred running maximum   :93/:95/:99 raise m for every tile.  The kernels keep m while no row of a G-row group
+ *                              (one wave's query block) has rowmax(S) - m > thr, so P = exp2(S - m) may reach 2^thr
+ *                              (fa2_a64.hip: thr = 60 bf16 / 12 f16; fa2_mfma8x.hip: kThr = 6); when one does, every
+ *                              row of the group takes m' = max(m, rowmax(S)).  thr < 0 raises m for every tile (= :93).
+ *   one rounding in S - m      exp2(fma(dot, c, -m)) instead of :92 + :94's two roundings;
+ *   sum_rounded != 0           l accumulates cast(P) (the row sums ride on the matrix pipe with the rounded P) instead
+ *                              of :96's unrounded P.
+ * Everything else (fp32 state, RTNE casts, :105-108) is the function above.  N need not be a multiple of G or B_c.
+ */
+int fa2_oracle_fwd_deferred(const float *Q, const float *K, const float *V, float *O, float *L,
+                            const int64_t qs[4], const int64_t ks[4], const int64_t vs[4],
+                            const int64_t os[4], const int64_t ls[2], int B, int H, int N, int d, int dtype,
+                            int causal, float scale, int G, int B_c, float thr, int sum_rounded) {
+    if (!Q || !K || !V || !O || !L || B <= 0 || H <= 0 || N <= 0 || d <= 0 || G <= 0 || B_c <= 0) return -1;
+    const float c_log2e = (float)((double)scale * LOG2_E);
+    float *S = (float *)malloc(sizeof(float) * (size_t)G * B_c);
+    float *Oi = (float *)malloc(sizeof(float) * (size_t)G * d);
+    float *m = (float *)malloc(sizeof(float) * G);
+    float *l = (float *)malloc(sizeof(float) * G);
+    float *mx = (float *)malloc(sizeof(float) * G);
+    if (!S || !Oi || !m || !l || !mx) return -1;
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H; ++h)
+            for (int q0 = 0; q0 < N; q0 += G) {
+                const float *Qb = Q + b * qs[0] + h * qs[1];
+                const float *Kb = K + b * ks[0] + h * ks[1];
+                const float *Vb = V + b * vs[0] + h * vs[1];
+                const int rows = N - q0 < G ? N - q0 : G;
+                for (int r = 0; r < rows; ++r) {
+                    m[r] = -INFINITY;
+                    l[r] = 0.0f;
+                }
+                memset(Oi, 0, sizeof(float) * (size_t)G * d);
+                const int kend = causal ? (q0 + rows < N ? q0 + rows : N) : N;
+                for (int k0 = 0; k0 < kend; k0 += B_c) {
+                    const int cols = kend - k0 < B_c ? kend - k0 : B_c;
+                    int fire = 0;
+                    for (int r = 0; r < rows; ++r) {
+                        const int qrow = q0 + r;
+                        const float *q = Qb + (int64_t)qrow * qs[2];
+                        mx[r] = -INFINITY;
+                        for (int c = 0; c < cols; ++c) {
+                            const int krow = k0 + c;
+                            const float *k = Kb + (int64_t)krow * ks[2];
+                            float acc = 0.0f;
+                            for (int x = 0; x < d; ++x) acc += q[x * qs[3]] * k[x * ks[3]];
+                            if (causal && krow > qrow) acc = -INFINITY;
+                            S[r * B_c + c] = acc;
+                            if (acc > mx[r]) mx[r] = acc;
+                        }
+                        mx[r] *= c_log2e;
+                        if (!(mx[r] - m[r] <= thr)) fire = 1;
+                    }
+                    for (int r = 0; r < rows; ++r) {
+                        float *o = Oi + (size_t)r * d;
+                        if (fire || thr < 0.0f) {
+                            const float m_new = m[r] > mx[r] ? m[r] : mx[r];
+                            const float coeff = exp2f(m[r] - m_new);
+                            l[r] *= coeff;
+                            for (int x = 0; x < d; ++x) o[x] *= coeff;
+                            m[r] = m_new;
+                        }
+                        for (int c = 0; c < cols; ++c) {
+                            const float p = exp2f(fmaf(S[r * B_c + c], c_log2e, -m[r]));
+                            const float pr = round_dtype(p, dtype);
+                            l[r] += sum_rounded ? pr : p;
+                            if (pr == 0.0f) continue;
+                            const float *v = Vb + (int64_t)(k0 + c) * vs[2];
+                            for (int x = 0; x < d; ++x) o[x] += pr * v[x * vs[3]];
+                        }
+                    }
+                }
+                for (int r = 0; r < rows; ++r) {
+                    const int qrow = q0 + r;
+                    float *o = O + b * os[0] + h * os[1] + (int64_t)qrow * os[2];
+                    for (int x = 0; x < d; ++x) o[x * os[3]] = round_dtype(Oi[(size_t)r * d + x] / l[r], dtype);
+                    L[b * ls[0] + h * ls[1] + qrow] = round_dtype(m[r] + log2f(l[r]), dtype);
+                }
+            }
+    free(S);
+    free(Oi);
+    free(m);
+    free(l);
+    free(mx);
+    return 0;
+}
+
+/*
  * fp64 entry.  The reference maps torch.float64 (flash_attention_torch.py:8-9) but its kernel
  * cannot run that dtype (tl.dot with an fp32 accumulator asserts; verified under the Triton
  * interpreter) -> "parity unpinned".  We define it as the same algorithm carried in double.

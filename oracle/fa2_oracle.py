@@ -42,6 +42,9 @@ def lib():
         _lib.fa2_oracle_fwd.restype = ctypes.c_int
         _lib.fa2_oracle_fwd.argtypes = [fp, fp, fp, fp, fp, i64p, i64p, i64p, i64p, i64p] + \
             [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
+        _lib.fa2_oracle_fwd_deferred.restype = ctypes.c_int
+        _lib.fa2_oracle_fwd_deferred.argtypes = [fp, fp, fp, fp, fp, i64p, i64p, i64p, i64p, i64p] + \
+            [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
         _lib.fa2_oracle_fwd_f64.restype = ctypes.c_int
         _lib.fa2_oracle_fwd_f64.argtypes = [dp, dp, dp, dp, dp, i64p, i64p, i64p, i64p, i64p] + \
             [ctypes.c_int] * 5 + [ctypes.c_double]
@@ -86,6 +89,23 @@ def forward(Q, K, V, dtype="float32", causal=False, scale=1.0, B_r=16, B_c=16):
                               int(bool(causal)), float(scale), B_r, B_c)
     if rc != 0:
         raise ValueError(f"fa2_oracle_fwd rc={rc} (N={N} must be a multiple of B_r={B_r}, B_c={B_c})")
+    return O, L
+
+
+def forward_deferred(Q, K, V, dtype, causal=False, scale=1.0, G=32, B_c=64, thr=60.0, sum_rounded=True):
+    """fa2_oracle_fwd_deferred: the restatement with the MFMA kernels' deferred running maximum (per G-row group, threshold
+    thr in log2 units), the single-rounding exp2(fma(S, c, -m)) and row sums of the rounded P.  Any N."""
+    dt = DTYPE_NAMES[dtype] if isinstance(dtype, str) else int(dtype)
+    B, H, N, d = Q.shape
+    Q, K, V = (np.asarray(x, dtype=np.float32) for x in (Q, K, V))
+    O = np.empty((B, H, N, d), np.float32)
+    L = np.empty((B, H, N, 1), np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    rc = lib().fa2_oracle_fwd_deferred(p(Q), p(K), p(V), p(O), p(L), _strides(Q), _strides(K), _strides(V), _strides(O),
+                                       (ctypes.c_int64 * 2)(H * N, N), B, H, N, d, dt, int(bool(causal)), float(scale),
+                                       int(G), int(B_c), float(thr), int(bool(sum_rounded)))
+    if rc != 0:
+        raise ValueError(f"fa2_oracle_fwd_deferred rc={rc}")
     return O, L
 
 

@@ -118,6 +118,33 @@ def test_strided_inputs(oracle):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype, causal):
+    """the kernel's liberties are exactly the ones oracle.forward_deferred states (running maximum kept per 32-row query block
+    while no row of it exceeds m by 60 / 12 log2 units, exp2(fma), row sums of the rounded P): against THAT restatement the
+    result is compared element by element -- at least 99 % of O bit-identical; an element that differs is off by its own
+    rounding step plus at most one rounding step of P times max |V| (a P that v_exp_f32's last bit rounds the other way moves O
+    by its share p / l of V -- early causal rows have few keys and large shares).  What remains besides is the fp32 summation
+    order of the matrix pipe."""
+    B, H, N = 1, 2, 512
+    Q, K, V = rand3((B, H, N, 128), dtype, seed=77)
+    K[:, :, 300] = (Q[:, :, 200].float() * 0.45).to(dtype)     # one row's maximum jumps past the f16 threshold mid-way
+    O, L = a64(Q, K, V, causal)
+    f = lambda t: t.float().numpy()
+    O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
+                                           thr=60.0 if dtype == torch.bfloat16 else 12.0, sum_rounded=True)
+    O, O_ref = O.float(), torch.from_numpy(O_ref)
+    same = (O == O_ref).float().mean().item()
+    assert same >= 0.99, same
+    mant = 7 if dtype == torch.bfloat16 else 10
+    one_ulp = torch.exp2(torch.floor(torch.log2(O_ref.abs().clamp(min=2.0 ** -14))) - mant)
+    bound = one_ulp + 2.0 ** -(mant + 1) * V.float().abs().max()
+    assert ((O - O_ref).abs() <= bound).all(), ((O - O_ref).abs() / bound).max().item()
+    Lf, L_ref = L.float().flatten(), torch.from_numpy(L_ref).flatten()
+    assert (Lf == L_ref).float().mean() >= 0.97 and (Lf - L_ref).abs().max() <= 1.01 * ulp(dtype, L_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_rescale_branch_is_exercised(oracle, dtype):
     """the running maximum of one row jumps far beyond the deferral threshold (60 / 12 log2 units) in the last tiles, after O
     and l are non-zero: O *= coeff, l *= coeff are taken (cdna_hip_programming.md rule 26)"""

@@ -68,9 +68,8 @@ def _call(N=64, d=64, dtype=_lib.FA2_DTYPE_F32, ptr=0x1000, B=1, H=1, strides=No
     (dict(ptr=0), -1, "null"),
     (dict(B=0), -1, "positive"),
     (dict(N=0), -3, "N must be"),
-    (dict(d=48), -2, "power of two"),
-    (dict(d=8), -2, "power of two"),
-    (dict(d=1024), -2, "power of two"),
+    (dict(d=0), -1, "positive"),
+    (dict(d=1024), -2, "[1, 512]"),
     (dict(dtype=99), -2, "dtype"),
     (dict(strides=(-1, 1, 1, 1)), -1, "negative"),
     (dict(scale=float("nan")), -1, "NaN"),
@@ -124,12 +123,19 @@ def test_static_tile_table():
     assert q(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_MFMA16H
     assert q(1024, 64, _lib.FA2_DTYPE_F16)[0] in (_lib.VARIANT_MFMA16H, _lib.VARIANT_MFMA16D_W4)
     assert q(256, 128, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32
-    assert q(128, 32, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_GENERIC
+    assert q(128, 32, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32   # (d < 64: the d = 64 kernel with the missing columns zero-filled)
     assert q(128, 64, _lib.FA2_DTYPE_F64)[0] == _lib.VARIANT_GENERIC
     assert q(128, 128, _lib.FA2_DTYPE_F8E5M2)[0] in (_lib.VARIANT_MFMA8X, _lib.VARIANT_MFMA8X_W4)
     assert q(128, 64, _lib.FA2_DTYPE_F8E4M3)[0] == _lib.VARIANT_GENERIC
     # supported N domain is a superset of the reference's (multiples of 16, autotune_configs.py:176-187)
     for N in (16, 48, 100, 4096):
         assert q(N, 64, _lib.FA2_DTYPE_F32)[1] > 0
+    # head sizes that are not powers of two stay on the matrix cores when they are multiples of 8 (16-bit) / 4 (fp32): the
+    # kernels zero-fill the missing columns on load; anything else runs on the generic kernel
+    assert q(128, 40, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32
+    assert q(128, 8, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32
+    assert q(128, 96, _lib.FA2_DTYPE_BF16)[0] in (_lib.VARIANT_MFMA16, _lib.VARIANT_MFMA16_W8)
+    assert q(128, 36, _lib.FA2_DTYPE_F16)[0] == _lib.VARIANT_GENERIC
+    assert q(128, 37, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_GENERIC
     with pytest.raises(TypeError):
-        q(128, 24, _lib.FA2_DTYPE_F32)
+        q(128, 513, _lib.FA2_DTYPE_F32)

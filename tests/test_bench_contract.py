@@ -57,3 +57,22 @@ def test_query_tile_reports_the_variant_the_launch_takes():
     assert _lib.query_tile(4096, 128, _lib.FA2_DTYPE_BF16, True, B=4, H=32)[0] == _lib.VARIANT_A64
     j = _run([sys.executable, "bench.py", "--config", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert j["config"]["tile"]["variant"] == _lib.VARIANT_MFMA16K_R2K4 and "N=1024" in j["metric"]
+
+
+@pytest.mark.parametrize("mode", ["fwd", "bwd"])
+def test_sweep_writes_the_csv_the_reference_plot_script_reads(tmp_path, mode):
+    """benchmarks/bench_sweep.py = the reference's src/bench.py: the file name and schema src/plot_bench_results.py:41-57,
+    102-126 consumes -- an `N` column and one column of mean milliseconds per provider display name, among them the
+    reference's own `Torch Math [FLOAT16]` (src/bench.py:38-41)."""
+    import pandas as pd
+    out = subprocess.run([sys.executable, "benchmarks/bench_sweep.py", "--n-max-log", "9", "--mode", mode, "--out-dir", str(tmp_path)],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    df = pd.read_csv(tmp_path / f"fused-attention-B8-H16-d128-{mode}-float16.csv", sep=",")   # plot_bench_results.py:53-57
+    df["N"] = df["N"].astype("int32")                                                           # plot_bench_results.py:73
+    assert list(df["N"]) == [128, 256, 512]
+    cols = [c for c in df.columns if c != "N"]
+    assert "MI355X HIP FA-2 [FLOAT16]" in cols and "Torch Math [FLOAT16]" in cols and "Torch FA-2 [FLOAT16]" in cols
+    assert (df["MI355X HIP FA-2 [FLOAT16]"] > 0).all() and (df["Torch Math [FLOAT16]"] > 0).all()
+    tf = pd.read_csv(tmp_path / f"fused-attention-B8-H16-d128-{mode}-float16-tflops.csv")
+    assert list(tf.columns) == list(df.columns) and (tf["MI355X HIP FA-2 [FLOAT16]"] > 0).all()

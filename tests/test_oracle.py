@@ -178,3 +178,34 @@ def test_fp64_entry_matches_numpy(oracle):
         O, L = oracle.forward(Q, K, V, "float64", causal=causal)
         O2, L2 = oracle.sdpa_f64(Q, K, V, causal=causal)
         assert np.abs(O - O2).max() < 1e-12 and np.abs(L - L2).max() < 1e-12
+
+
+def test_deferred_maximum_mode_is_the_pinned_oracle_up_to_its_stated_liberties(oracle):
+    """oracle.forward_deferred (the restatement with the MFMA kernels' deferred running maximum, single-rounding exp2(fma) and
+    row sums of the rounded P) against the pinned restatement and the reference's own vectors: with the threshold disabled it is
+    the reference schedule up to one fp32 rounding; with the kernels' thresholds it stays inside the parity tolerances."""
+    g = load_golden("c1_f32_seed0")
+    O, L = oracle.forward_deferred(g["Q"], g["K"], g["V"], "float32", G=32, B_c=64, thr=-1.0, sum_rounded=False)
+    assert np.abs(O - g["O_ref_32x64"]).max() < 1e-5 and close(O, g["O_sdpa"])   # (the plain restatement: 3e-6)
+    assert np.abs(L[..., 0] - g["L_ref_32x64"].reshape(L.shape[:3])).max() < 2e-5
+    O, L = oracle.forward_deferred(g["Q"], g["K"], g["V"], "float32", G=32, B_c=64, thr=60.0, sum_rounded=True)
+    assert close(O, g["O_sdpa"])
+    g = load_golden("c1_bf16_seed4")
+    Q, K, V = (bf16_bits_to_f32(g[k]) for k in "QKV")
+    for causal, key in ((False, "O_sdpa"), (True, "O_sdpa_causal")):
+        Op, _ = oracle.forward(Q, K, V, "bfloat16", causal=causal, B_r=32, B_c=64)
+        Od, _ = oracle.forward_deferred(Q, K, V, "bfloat16", causal=causal, G=32, B_c=64, thr=-1.0, sum_rounded=False)
+        assert (Op == Od).mean() > 0.999                       # same schedule: only exp2(fma) vs two roundings differs
+        Ok, _ = oracle.forward_deferred(Q, K, V, "bfloat16", causal=causal, G=32, B_c=64, thr=60.0, sum_rounded=True)
+        assert np.abs(Ok - g[key]).max() < 2.5e-2              # the bar test_causal_and_bf16_extensions_match_sdpa uses
+    g = load_golden("f8e5m2_seed10")
+    Q, K, V = (f8_to_f32(g[k], torch.float8_e5m2) for k in "QKV")
+    Op, Lp = oracle.forward(Q, K, V, "float8_e5m2", B_r=32, B_c=64)
+    Od, Ld = oracle.forward_deferred(Q, K, V, "float8_e5m2", G=32, B_c=64, thr=-1.0, sum_rounded=False)
+    assert (Op == Od).mean() > 0.995 and (Lp == Ld).mean() > 0.98
+    # ragged N and a group size that does not divide it
+    rng = np.random.default_rng(3)
+    Q, K, V = (rng.standard_normal((1, 2, 77, 32)).astype(np.float32) for _ in range(3))
+    Od, Ld = oracle.forward_deferred(Q, K, V, "float32", causal=True, G=32, B_c=64, thr=60.0)
+    O64, L64 = oracle.sdpa_f64(Q, K, V, causal=True)
+    assert np.abs(Od - O64).max() < 1e-5 and np.abs(Ld - L64).max() < 1e-4
