@@ -10,6 +10,10 @@ every instruction in between counts one, `s_nop N` counts N + 1):
   R6  VALU-written SGPR (v_readfirstlane, v_cmp) -> VMEM / SMEM / SALU reader: >= 5 (only VMEM needs it; kept strict)
   R7  SALU write of M0 -> LDS-DMA: >= 1
   R8  MFMA C operand -> overwritten by VALU: >= 12
+  R9  (not a wait state: a scheduling invariant) the SCC an instruction consumes was produced by the instruction meant to
+      produce it -- s_addc_u32 by the s_add_u32 of the low half of its own register pair, s_cselect / s_cbranch_scc* by a
+      compare -- with no label in between.  Interleaving scalar sequences into MFMA gaps one instruction at a time broke a
+      64-bit carry chain this way (a descriptor base lost its carry whenever the low word overflowed).
 The scan is linear over the listing (labels do not reset it): blocks reached by a taken branch must open with their own pad.
 """
 from __future__ import annotations
@@ -38,6 +42,10 @@ def fix(prog, max_rounds=64):
         errs = check(prog, verbose=False)
         if not errs:
             return prog, added
+        if any(rule.startswith("R9") for _, rule, _, _ in errs):
+            bad = [idx for idx, rule, _, _ in errs if rule.startswith("R9")]
+            raise RuntimeError(f"SCC consumed from the wrong producer at instruction(s) {bad[:8]}: "
+                               f"{prog[bad[0]].text().strip()} (keep scalar carry / compare sequences in one filler unit)")
         need = {}
         for idx, rule, _, dist in errs:
             need[idx] = max(need.get(idx, 0), REQUIRED[rule.split()[0]] - dist)
@@ -50,6 +58,31 @@ def fix(prog, max_rounds=64):
                 n -= min(n, 16)
             prog[idx:idx] = pads
     raise RuntimeError("hazard fixer did not converge")
+
+
+def check_scc(prog):
+    """rule R9; returns [(index, rule text, ("scc", 0), 0)]"""
+    errs = []
+    last = None
+    for idx, ins in enumerate(prog):
+        if ins.op == ".label":
+            last = None
+            continue
+        if ins.op == ".comment":
+            continue
+        d, u = ins.defs_uses()
+        if ("scc", 0) in u:
+            if last is None:
+                ok = False
+            elif ins.op == "s_addc_u32":
+                ok = last.op == "s_add_u32" and last.ops[0].kind == ins.ops[0].kind and last.ops[0].idx + 1 == ins.ops[0].idx
+            else:
+                ok = last.op.startswith("s_cmp") or last.op.startswith("s_bitcmp")
+            if not ok:
+                errs.append((idx, "R9 scc producer", ("scc", 0), 0))
+        if ("scc", 0) in d:
+            last = ins
+    return errs
 
 
 def check(prog, verbose=True):
@@ -137,6 +170,7 @@ def check(prog, verbose=True):
                     if r == ("s", 124):
                         last_m0 = here
         pos += ws
+    errs += check_scc(prog)
     if verbose:
         for idx, rule, r, dd in errs[:40]:
             print(f"  hazard {rule}: inst {idx} `{prog[idx].text().strip()}` reg {r} distance {dd}")

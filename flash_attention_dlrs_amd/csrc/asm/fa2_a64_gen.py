@@ -125,7 +125,7 @@ NSLOT = 24
 
 
 class Gen:
-    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2)):
+    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
@@ -136,6 +136,7 @@ class Gen:
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
+        self.vread_double = vread_double   # phase-A gaps that carry two V transposed reads (the last read sits in gap 31 - this)
         self.abl = set(abl)    # timing-only ablations of the steady loop (diagnostic builds; results wrong by construction)
         self.R, self.dk, self.dv = ring   # ring depth; K(t + dk) and V(t + dv) are streamed in phase B(t): dk <= R + 1, dv <= R
         assert 3 <= self.dk <= min(self.R + 1, 4) and 2 <= self.dv <= self.R and 4 % self.R == 0
@@ -533,10 +534,10 @@ class Gen:
         # phase B: the gap behind a 16x16x32 row-sum MFMA is half as long
         for b in self.b_short_gaps():
             cap_s[32 + b], cap_c[32 + b] = 2.0, 8.0
-        # pre-reserved: one V transposed read per phase-A gap; K reads, DMA pieces and their scalar set-up in phase B
-        for g in range(32):
-            slots[g] += 1
-            cost[g] += 2
+        # pre-reserved: the V transposed reads of phase A; K reads, DMA pieces and their scalar set-up in phase B
+        for k in range(32):
+            slots[self.a_vread_gap(k)] += 1
+            cost[self.a_vread_gap(k)] += 2
         for b, n in self.b_reserved().items():
             slots[32 + b] += n
             cost[32 + b] += 3 * n
@@ -593,6 +594,12 @@ class Gen:
         assert max(t for t, _, _ in placed) < self.T_END, max(t for t, _, _ in placed)
         self._cache[key] = placed
         return placed
+
+    def a_vread_gap(self, k):
+        """phase-A gap of V transposed read k: two per gap at the start, none in the last four -- the wait in front of the barrier
+        then finds the youngest read ~130 cycles old instead of just issued"""
+        nd = self.vread_double
+        return k // 2 if k < 2 * nd else k - nd
 
     def b_short_gaps(self):
         """indices (0..39) of the phase-B gaps that follow a 16x16x32 row-sum MFMA"""
@@ -737,7 +744,7 @@ class Gen:
         if cur:
             if "novread" not in abl:
                 for k, ins in enumerate(self.v_reads(t4 % self.R)):
-                    add(k, 0, [ins])
+                    add(self.a_vread_gap(k), 0, [ins])
             if "nofinish" not in abl:
                 for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False, abl=abl):
                     add(k, 1 if is_exp else 2, ins)
@@ -798,9 +805,19 @@ class Gen:
                 add(g - 1, 3, setup)
                 add(g, 0, load if mf else [I("s_nop", 0)] + load)
             post += [I("s_add_u32", S_VDMA, S_VDMA, S_V64), I("s_add_u32", S_KDMA, S_KDMA, S_K64)]
-        ne = len(early)
-        for k, ins in enumerate(early):
-            add(1 + 12 * k // max(ne, 1), 2, [ins])   # done before this phase's own DMA pieces (gap 15 on) and the late ones
+        # scalar work rides in the first gaps one UNIT at a time: an instruction that consumes SCC (the s_addc of a 64-bit
+        # add, a select or branch on a compare) stays glued to the instructions since its producer -- other fillers write
+        # SCC too (the DMA set-up's s_add_u32), and a descriptor base once lost its carry that way (check.py R9)
+        units = []
+        for ins in early:
+            d_, u_ = ins.defs_uses()
+            if ("scc", 0) in u_ and units:
+                units[-1].append(ins)
+            else:
+                units.append([ins])
+        ne = len(units)
+        for k, unit in enumerate(units):
+            add(1 + 12 * k // max(ne, 1), 2, unit)   # done before this phase's own DMA pieces (gap 15 on) and the late ones
         for k, pc in enumerate(late):   # whole units (they set M0 and a scratch offset): never between a piece's set-up and its load
             add(20 + (NB - 21) * k // max(len(late), 1), 2, pc)
         if nxt and "nostart" not in abl:
@@ -1095,6 +1112,10 @@ def main(argv=None):
         g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite", stamps=True, abl=("lite",))
         g.build()
         gens.append(g)
+        for nd in (0, 8, 12, 16):   # placement experiments of the V reads (correct kernels)
+            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_vr{nd}", stamps=True, abl=("lite",), vread_double=nd)
+            g.build()
+            gens.append(g)
         for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
             g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
             g.build()

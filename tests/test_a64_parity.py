@@ -158,6 +158,40 @@ def test_rescale_branch_is_exercised(oracle, dtype):
         check(*a64(Q, K, V, causal), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
 
 
+@pytest.mark.parametrize("variant", ["a64", "mfma16h", "mfma16"])
+def test_tensors_that_straddle_a_4_gib_address_boundary(variant):
+    """every 64-bit address the kernels form (descriptor base + b * stride_b + h * stride_h) must carry out of its low word:
+    Q, K, V, O and L are placed so that each crosses a 4-GiB-aligned device address inside its own arena.  (The a64 seam once
+    lost exactly that carry: a DMA set-up's s_add_u32 sat between the s_add_u32 / s_addc_u32 of the next job's Q descriptor.)"""
+    dtype = torch.bfloat16
+    B, H, N, d = 2, 80, 512, 128     # 320 jobs of 256 rows on 256 workgroups: job seams (the next job's descriptors) included
+    gen = torch.Generator().manual_seed(5)
+    src = [torch.randn(B, H, N, d, generator=gen).to(dtype) for _ in range(3)]
+    GiB = 1 << 30
+
+    def straddling(shape, dt):
+        nbytes = math.prod(shape) * torch.empty((), dtype=dt).element_size()
+        arena = torch.empty(4 * GiB + 2 * nbytes + 4096, dtype=torch.uint8, device=DEV)
+        edge = (arena.data_ptr() + nbytes + 4 * GiB - 1) // (4 * GiB) * (4 * GiB)      # first 4-GiB multiple past ptr + nbytes
+        start = edge - nbytes // 2 - (edge - nbytes // 2) % 256                          # the tensor's middle sits on the edge
+        off = start - arena.data_ptr()
+        assert 0 <= off and off + nbytes <= arena.numel() and start < edge < start + nbytes
+        return arena, arena[off:off + nbytes].view(dt).view(shape)
+    keep, tens = zip(*[straddling((B, H, N, d), dtype) for _ in range(4)])
+    Q, K, V, O = tens
+    _, L = straddling((B, H, N, 1), dtype)
+    for t, s_ in zip((Q, K, V), src):
+        t.copy_(s_)
+    _lib.fa2_fwd(Q, K, V, O, L, _lib.FA2_DTYPE_BF16, causal=True, variant=_lib.VARIANTS[variant])
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.scaled_dot_product_attention(*(t.float() for t in (Q, K, V)), scale=1.0, is_causal=True)
+    assert (O.float() - ref).abs().max().item() <= O_TOL[dtype]
+    S = (Q.float() @ K.float().transpose(-1, -2)).masked_fill(~torch.ones(N, N, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+    L_ref = torch.logsumexp(S, dim=-1, keepdim=True) * math.log2(math.e)
+    assert (L.float() - L_ref).abs().max().item() <= 1.01 * ulp(dtype, L_ref.abs().max().item())
+    del keep
+
+
 @pytest.mark.parametrize("variant", ["a64", "mfma16h", "mfma16d_w4"])
 def test_nan_and_inf_inputs_propagate_like_the_oracle(oracle, variant):
     """A NaN in Q poisons its row, a NaN in V its column of the rows that see it, a NaN key every row that sees it; +Inf in V

@@ -84,3 +84,18 @@ def test_emulated_kernel_frequent_rescales_across_jobs(oracle):
 
 def test_emulated_kernel_rescale_path(oracle):
     _run(oracle, "bf16", False, 1, 1, 512, spike=True, seed=2)
+
+
+def test_scc_producer_rule_catches_a_broken_carry_chain():
+    """check.py R9: an s_addc_u32 must take its carry from the s_add_u32 of its own pair (a filler that writes SCC in between --
+    here a DMA set-up's s_add_u32 -- silently drops the carry of a 64-bit address)"""
+    from flash_attention_dlrs_amd.csrc.asm.check import check_scc, fix
+    from flash_attention_dlrs_amd.csrc.asm.isa import I, M0, S
+    good = [I("s_add_u32", S(88), S(88), S(94)), I("s_addc_u32", S(89), S(89), S(95))]
+    assert check_scc(good) == []
+    bad = [good[0], I("s_add_u32", M0, S(78), 0x8400), good[1]]
+    assert [e[1] for e in check_scc(bad)] == ["R9 scc producer"]
+    with pytest.raises(RuntimeError, match="SCC consumed from the wrong producer"):
+        fix(bad)
+    assert check_scc([I("s_cmp_lg_u32", S(80), 0), I("s_cbranch_scc1", "x")]) == []
+    assert len(check_scc([I("s_cmp_lg_u32", S(80), 0), I("s_add_u32", S(70), S(70), S(76)), I("s_cbranch_scc1", "x")])) == 1
