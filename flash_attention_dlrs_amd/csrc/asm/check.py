@@ -41,7 +41,22 @@ def fix(prog, max_rounds=64):
     for _ in range(max_rounds):
         errs = check(prog, verbose=False)
         if not errs:
-            return prog, added
+            # taken branches: pad behind the target label by what the path into it lacks
+            bt = check_branch_targets(prog)
+            if not bt:
+                return prog, added
+            need_at = {}
+            for _, tgt, _, short in bt:
+                need_at[tgt] = max(need_at.get(tgt, 0), short)
+            for tgt in sorted(need_at, reverse=True):
+                n = need_at[tgt]
+                added += n
+                pads = []
+                while n > 0:
+                    pads.append(Inst("s_nop", (min(n, 16) - 1,), {}, "wait states behind a taken branch (check.fix)"))
+                    n -= min(n, 16)
+                prog[tgt + 1:tgt + 1] = pads
+            continue
         if any(rule.startswith("R9") for _, rule, _, _ in errs):
             bad = [idx for idx, rule, _, _ in errs if rule.startswith("R9")]
             raise RuntimeError(f"SCC consumed from the wrong producer at instruction(s) {bad[:8]}: "
@@ -82,6 +97,52 @@ def check_scc(prog):
                 errs.append((idx, "R9 scc producer", ("scc", 0), 0))
         if ("scc", 0) in d:
             last = ins
+    return errs
+
+
+def check_branch_targets(prog, need=12):
+    """out-of-line blocks are scanned by check() where they stand in the listing, not where they are entered from: for every
+    branch, the registers the target block touches before its first branch out must be `need` wait states clear of the last
+    MFMA that wrote them on the path INTO the branch (rule R1 across a taken branch).
+    Returns [(branch index, target label index, reg, missing wait states)]"""
+    labels = {ins.ops[0].name: i for i, ins in enumerate(prog) if ins.op == ".label"}
+    errs = []
+    for bi, br in enumerate(prog):
+        if not (br.op.startswith("s_cbranch") or br.op == "s_branch"):
+            continue
+        tgt = labels.get(getattr(br.ops[0], "name", None))
+        if tgt is None:
+            continue
+        # registers touched after the label, each with the wait states the block itself puts in front of the touch
+        first_touch = {}
+        ahead = 0
+        for ins in prog[tgt + 1:tgt + 200]:
+            if ins.op in (".label", ".comment"):
+                continue
+            if ins.op.startswith("s_branch") or ins.op == "s_endpgm" or ahead >= need:
+                break
+            if ins.op != "s_nop" and not ins.is_mfma:   # (MFMA after MFMA: the linear scan's business)
+                d, u = ins.defs_uses()
+                for r in list(d) + list(u):
+                    if r[0] in ("v", "a"):
+                        first_touch.setdefault(r, ahead)
+            ahead += wait_states(ins)
+        if not first_touch:
+            continue
+        dist = 1   # the branch itself
+        worst = None
+        for ins in reversed(prog[max(0, bi - 400):bi]):
+            if ins.op == ".label" or dist >= need:   # (a join point: paths into it are checked where they branch)
+                break
+            if ins.is_mfma:
+                for r in ins.ops[0].regs():
+                    if r in first_touch and dist + first_touch[r] < need:
+                        short = need - dist - first_touch[r]
+                        if worst is None or short > worst[1]:
+                            worst = (r, short)
+            dist += wait_states(ins)
+        if worst:
+            errs.append((bi, tgt, worst[0], worst[1]))
     return errs
 
 

@@ -699,7 +699,8 @@ class Gen:
         (qb1, kb1) get the triangle (key > query -> -inf), (qb0, kb1) is all -inf; w < jd: all -inf.  Register r of a
         group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i.  cond: (sgpr, value): the tile is diagonal at all.
         Returns the in-line tests for score group g (in front of its first row-maximum operation); the masking itself runs
-        out of line and opens with the MFMA -> VALU wait states."""
+        out of line.  The branch sits where that row-maximum operation is legal, i.e. the MFMA -> VALU wait states have passed
+        (check.check_branch_targets verifies it on the built program)."""
         l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
         out = []
         if cond is not None:
@@ -714,10 +715,10 @@ class Gen:
             eq_ops = [I("v_mov_b32", V(Y + 16 + r), ninf) for r in range(16)]
         if eq_ops:
             out += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
-            self.ool.append([label(l_eq), I("s_nop", 11)] + eq_ops + [I("s_branch", Label(l_back))])
+            self.ool.append([label(l_eq)] + eq_ops + [I("s_branch", Label(l_back))])
         if jd > 0:
             out += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
-            self.ool.append([label(l_lt), I("s_nop", 11)] + [I("v_mov_b32", V(Y + 16 * g + r), ninf) for r in range(16)] +
+            self.ool.append([label(l_lt)] + [I("v_mov_b32", V(Y + 16 * g + r), ninf) for r in range(16)] +
                             [I("s_branch", Label(l_back))])
         out += [label(l_back)]
         return out
@@ -1047,8 +1048,10 @@ class Gen:
         e(label(l_end), waitcnt(vmcnt=0), self.stamp(7, real=True), self.stamp(9), I("s_endpgm"))
         for blk in self.ool:
             e(blk)
-        from .check import fix
+        from .check import check_branch_targets, fix
         self.prog, self.pads = fix(self.prog)
+        bad = check_branch_targets(self.prog)
+        assert not bad, ("a branch enters a block that touches fresh MFMA results", bad[:4])
         return self.prog
 
     # ------------------------------------------------------------------ text
