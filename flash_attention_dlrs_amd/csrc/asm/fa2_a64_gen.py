@@ -425,7 +425,8 @@ class Gen:
                   I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
                   I("s_lshl_b32", S_T[3], S_QSN, 3),                    # 8 rows
                   I("s_lshl_b32", S_T[4], S_WAVE, 14), I("s_add_u32", S_T[4], S_T[4], EPI)]
-        pieces = []
+        pieces = []   # (scalar set-up, load): the set-up ends one MFMA gap, the load opens the next (the MFMA between them is the
+        # wait state the M0 write needs), like the K / V pieces of phase B
         for R in range(8):
             for half in range(2):
                 pc = []
@@ -433,11 +434,11 @@ class Gen:
                 if half:
                     so = S_T[5]
                     pc.append(I("s_add_u32", so, S_T[2], 128))
-                pc += [I("s_add_u32", M0, S_T[4], 2048 * R + 1024 * half), I("s_nop", 0),
-                       I("buffer_load_dwordx4", V(V_DQO if R & 1 else V_DQE), S_SQ, so, offen=1, lds=1, tag=f"qdma R{R} h{half}")]
-                if half and R < 7:
-                    pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
-                pieces.append(pc)
+                    if R < 7:
+                        pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
+                pc.append(I("s_add_u32", M0, S_T[4], 2048 * R + 1024 * half))
+                ld = I("buffer_load_dwordx4", V(V_DQO if R & 1 else V_DQE), S_SQ, so, offen=1, lds=1, tag=f"qdma R{R} h{half}")
+                pieces.append((pc, ld))
         return setup, pieces
 
     def q_reads(self):
@@ -733,7 +734,7 @@ class Gen:
                 out += ins
         return out
 
-    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False):
+    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=()):
         """A(t), t4 = t & 3: QK^T(t+1) -> S[1-p]  ||  V(t) reads from VB[t % R]  ||  the late softmax operations of tile t (on S[p])
         ||  the early ones of tile t+1 (on S[1-p])"""
         p = t4 & 1
@@ -752,6 +753,9 @@ class Gen:
         if nxt and "nostart" not in abl:
             for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks, abl=abl):
                 add(k, 1 if is_exp else 2, ins)
+        for g, setup, load in dma:   # LDS-DMA pieces riding in this phase (the seam's Q rows): set-up ends gap g - 1, load opens gap g
+            add(g - 1, 3, setup)
+            add(g, 0, [load])
         if not mf:
             return [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
         return self.emit_phase(mf, gaps)
@@ -774,11 +778,11 @@ class Gen:
         return out
 
     def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
-                pre=(), early=(), late=(), masks=None):
+                pre=(), early=(), late=(), masks=None, own_gaps=None):
         """B(t), t4 = t & 3: P.V(t) and the row sums of P(t) from S[p]  ||  the middle softmax operations of tile t+1 (on S[1-p])
         ||  K(t+2) reads from KB[(t+2) % R]  ||  LDS-DMA V(t+dv) -> VB[(t+dv) % R], K(t+dk) -> KB[(t+dk) % R].
         pre: instructions ahead of the phase;  early: scalar work / register loads spread over the first gaps;
-        late: further DMA pieces (the next job's Q rows) behind this step's own"""
+        late: further DMA pieces (the next job's Q rows) as (gap, set-up, load);  own_gaps: the gaps of this step's own pieces"""
         p = t4 & 1
         X, Y = SBUF[p], SBUF[1 - p]
         abl = self.abl if steady else set()
@@ -799,7 +803,7 @@ class Gen:
                     continue
                 # (with further pieces behind them -- the seam's Q rows -- this step's own go first: the counted waits
                 # assume all eight are older than the sixteen)
-                g = self.b_dma_gap(k) if not late else (1, 3, 5, 7, 11, 13, 15, 17)[k]
+                g = own_gaps[k] if own_gaps else self.b_dma_gap(k)
                 # scalar set-up (soffset, M0) at the end of the previous gap, the load first in its own: the MFMA between
                 # them is the wait state the M0 write needs
                 setup, load = [x for x in pc if not x.op.startswith("buffer_load") and x.op != "s_nop"], [x for x in pc if x.op.startswith("buffer_load")]
@@ -819,8 +823,9 @@ class Gen:
         ne = len(units)
         for k, unit in enumerate(units):
             add(1 + 12 * k // max(ne, 1), 2, unit)   # done before this phase's own DMA pieces (gap 15 on) and the late ones
-        for k, pc in enumerate(late):   # whole units (they set M0 and a scratch offset): never between a piece's set-up and its load
-            add(20 + (NB - 21) * k // max(len(late), 1), 2, pc)
+        for g, setup, load in late:   # (gap pairs disjoint from the own pieces': both use M0 and the scratch offset register)
+            add(g - 1, 3, setup)
+            add(g, 0, [load])
         if nxt and "nostart" not in abl:
             for k, ins, is_exp in self.tile_fill(Y, 32, 32 + NB, nxt_init, masks, abl=abl):
                 add(k, 1 if is_exp else 2, ins)
@@ -863,8 +868,9 @@ class Gen:
 
     def step(self, t4, a_pre=(), **kw):
         """one tile step, t4 = t & 3"""
-        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady")}
-        kb = {k: v for k, v in kw.items() if k in ("with_pv", "nxt", "nxt_init", "with_kread", "with_dma", "steady", "pre", "early", "late")}
+        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady", "dma")}
+        kb = {k: v for k, v in kw.items() if k in ("with_pv", "nxt", "nxt_init", "with_kread", "with_dma", "steady", "pre", "early", "late",
+                                                   "own_gaps")}
         if kw.get("masks") is not None:   # the masking tests of a score group sit in front of its first row-maximum operation
             ka["masks"] = kw["masks"]
             kb["masks"] = kw["masks"]
@@ -988,7 +994,7 @@ class Gen:
             if j < self.dv - 1:
                 e(self.dma_tile("v", j % self.R))
         qs_setup, qs_pieces = self.q_stage(S_B, S_HH, S_QI)
-        e(qs_setup, qs_pieces)
+        e(qs_setup, [pc + [I("s_nop", 0), ld] for pc, ld in qs_pieces])
         e([I("v_accvgpr_write_b32", A(k), 0) for k in range(128)])   # O^T := 0
         e(waitcnt(vmcnt=0), I("s_barrier"))
         e(self.stamp(1))
@@ -1020,12 +1026,17 @@ class Gen:
                 kw = dict(masks=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None)
                 early, pre = [], []
                 if st == 0:
-                    # the next job's Q rows start their way into the wave's LDS slice, BEHIND this step's K / V pieces; the
-                    # next barrier wait leaves them in flight (vmcnt(16 + ...)), the one after retires them
+                    # the next job's Q rows start their way into the wave's LDS slice: sixteen pieces, never more than one
+                    # DMA piece per two gaps (that rate is free beside the MFMAs): eight behind this step's own K / V pieces,
+                    # four in the quiet end of the next phase A, four in front of the next step's own.  The barrier waits
+                    # in between leave them in flight (vmcnt(8 / 12 + ...)); the one of step 2 retires them
                     early += qs_setup
-                    kw.update(late=qs_pieces)
+                    kw.update(own_gaps=(1, 3, 5, 7, 11, 13, 15, 17),
+                              late=[(g, *qs_pieces[k]) for k, g in enumerate((21, 23, 25, 27, 31, 33, 35, 37))])
                 if st == 1:
-                    kw.update(vm=self.vm + 16)
+                    kw.update(vm=self.vm + 12,
+                              dma=[(g, *qs_pieces[8 + k]) for k, g in enumerate((24, 26, 28, 30))],
+                              late=[(g, *qs_pieces[12 + k]) for k, g in enumerate((1, 3, 5, 7))])
                 if st == sk:
                     early += kpre
                 if st == sv:
