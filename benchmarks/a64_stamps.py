@@ -63,6 +63,12 @@ for k, nm in ((10, "phaseA"), (11, "sync"), (12, "phaseB")):
     out[nm + "_cyc_per_step"] = [round(float(lo[:, w, k].double().median()) / steps, 1) for w in range(4)]
 out["seam_steps_cyc"] = [float((d[..., 17] - d[..., 16]).median()), float((d[..., 18] - d[..., 17]).median()),
                          float((d[..., 19] - d[..., 18]).median()), float((d[..., 4] - d[..., 19]).median()), float((d[..., 16] - d[..., 3]).median())]
+# inside the epilogue (slot 4 = its start): L + descriptors | block 0 scale/pack/write + read-back issue | block 1 first half |
+# block 0 stores + block 1 second half + read-back issue | O := 0 | block 1 stores
+pts = [d[..., 4], d[..., 13], d[..., 14], d[..., 15], d[..., 20], d[..., 21], d[..., 5]]
+out["epilogue_parts_cyc"] = [float((b - a).median()) for a, b in zip(pts[:-1], pts[1:])]
+if "lite" in os.environ.get("FA2_A64_KERNEL", ""):   # sums over all jobs of a workgroup: steady loops, seam bodies, epilogues, first fill
+    out["all_jobs_cyc"] = {nm: float(lo[:, 0, k].double().median()) for nm, k in (("steady", 10), ("seam", 11), ("epilogue", 12), ("fill", 22))}
 real = (d[..., 7] - d[..., 6]).median().item()  # 100 MHz ticks
 out["clock_ghz"] = round(float(seg["kernel"].median()) / real / 10.0, 3) if real > 0 else None
 out["job_cyc"] = float((d[..., 5] - d[..., 0]).median())

@@ -561,6 +561,15 @@ class Workgroup:
     def x_v_log_f32(self, w, i):
         w.wr_v(i.ops[0], np.log2(w.rd_f(i.ops[1]).astype(np.float64)).astype(np.float32))
 
+    def x_v_pk_mul_f32(self, w, i):
+        sel = i.mods.get("op_sel_hi", (1, 1))
+        a = [w.rd_v(i.ops[1], k).view(np.float32) for k in range(2)]
+        b = [w.rd_v(i.ops[2], k).view(np.float32) for k in range(2)]
+        lo = (a[0] * b[0]).astype(np.float32)
+        hi = (a[sel[0]] * b[sel[1]]).astype(np.float32)
+        w.wr_v(i.ops[0], lo, 0)
+        w.wr_v(i.ops[0], hi, 1)
+
     def x_v_mul_f32(self, w, i):
         w.wr_v(i.ops[0], (w.rd_f(i.ops[1]) * w.rd_f(i.ops[2])).astype(np.float32))
 

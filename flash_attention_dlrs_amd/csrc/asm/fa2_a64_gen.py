@@ -166,6 +166,24 @@ class Gen:
                 I("v_mov_b32", v.sub(0), t.sub(0)), I("v_mov_b32", v.sub(1), t.sub(1)),
                 I("v_mov_b32", V(V_T[7]), 0), I("global_store_dwordx2", V(V_T[7]), v, S_DBG, offset=8 * slot)]
 
+    ASYNC_PAIRS = (S(90, 2), S(92, 2), S(94, 2), S(0, 2), S(2, 2))   # S_T[2..7], S_FIRE: idle in the epilogue
+
+    def stamp_async(self, k):
+        """diagnostic builds only: s_memtime into spare pair k WITHOUT a wait (the epilogue's LDS queue is not drained; its
+        counted lgkmcnt waits may be satisfied early by the returning s_memtime: timing-only)"""
+        return [I("s_memtime", self.ASYNC_PAIRS[k])] if self.stamps else []
+
+    def stamp_async_flush(self, slots):
+        if not self.stamps:
+            return []
+        out = [waitcnt(lgkmcnt=0), I("v_mov_b32", V(V_T[7]), 0)]
+        v = V(V_T[8], 2)
+        for k, slot in enumerate(slots):
+            t = self.ASYNC_PAIRS[k]
+            out += [I("v_mov_b32", v.sub(0), t.sub(0)), I("v_mov_b32", v.sub(1), t.sub(1)),
+                    I("global_store_dwordx2", V(V_T[7]), v, S_DBG, offset=8 * slot), I("s_nop", 7)]
+        return out
+
     def stamp_acc(self, k):
         """diagnostic builds only: acc[k] += cycles since the previous stamp_acc (its s_waitcnt drains the LDS queue as well: the
         per-phase shares cost cycles of their own -- the "lite" kernels carry the job-level stamps only)"""
@@ -176,8 +194,26 @@ class Gen:
         return [I("s_memtime", t), waitcnt(lgkmcnt=0), I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)),
                 I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp), I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
 
+    def stamp_job(self, k):
+        """lite diagnostic builds: acc[k] += cycles since the previous stamp_job, summed over ALL jobs of the workgroup
+        (0 steady loops, 1 seam bodies, 2 epilogues + job bookkeeping, 3 the pipeline fill of the first job)"""
+        if not self.stamps or "lite" not in self.abl:
+            return []
+        t = S(S_T[0].idx, 2)
+        tmp = V(V_T[9])
+        return [I("s_memtime", t), waitcnt(lgkmcnt=0), I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)),
+                I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp), I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
+
+    def stamp_job_flush(self):
+        if not self.stamps or "lite" not in self.abl:
+            return []
+        out = [I("v_mov_b32", V(V_T[7]), 0)]
+        for k, slot in enumerate((10, 11, 12, 22)):
+            out += [I("global_store_dword", V(V_T[7]), V(V_ST_ACC + k), S_DBG, offset=8 * slot)]
+        return out
+
     def stamp_flush(self):
-        if not self.stamps:
+        if not self.stamps or "lite" in self.abl:
             return []
         out = [I("v_mov_b32", V(V_T[7]), 0)]
         for k in range(4):
@@ -703,9 +739,7 @@ class Gen:
         out of line.  The branch sits where that row-maximum operation is legal, i.e. the MFMA -> VALU wait states have passed
         (check.check_branch_targets verifies it on the built program)."""
         l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
-        out = []
-        if cond is not None:
-            out += [I("s_cmp_lg_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_back))]
+        tests = []
         ninf = V(V_NINF)
         eq_ops = []
         if g in (0, 3):
@@ -715,14 +749,21 @@ class Gen:
         elif g == 1:
             eq_ops = [I("v_mov_b32", V(Y + 16 + r), ninf) for r in range(16)]
         if eq_ops:
-            out += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
+            tests += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
             self.ool.append([label(l_eq)] + eq_ops + [I("s_branch", Label(l_back))])
         if jd > 0:
-            out += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
+            tests += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
             self.ool.append([label(l_lt)] + [I("v_mov_b32", V(Y + 16 * g + r), ninf) for r in range(16)] +
                             [I("s_branch", Label(l_back))])
-        out += [label(l_back)]
-        return out
+        if cond is None:
+            return tests + [label(l_back)]
+        if not tests:
+            return []
+        # the tile is diagonal only in the loop's last trip (or for a one-tile-row job): the common path falls through one
+        # compare and one untaken branch -- a TAKEN branch over the tests cost ~25 cycles per step in the steady loop
+        l_tests = self.lab("mask_tests")
+        self.ool.append([label(l_tests)] + tests + [I("s_branch", Label(l_back))])
+        return [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_tests)), label(l_back)]
 
     # ------------------------------------------------------------------ the two phases
     def emit_phase(self, mfmas, gaps):
@@ -888,14 +929,18 @@ class Gen:
 
     # ------------------------------------------------------------------ epilogue of the current job
     def k_epilogue(self):
+        """1 / l (one Newton step), L = m + log2 l, O^T -> rows through the wave's LDS slice -> 16-byte row stores, O^T := 0.
+        A workgroup's O tile is 64 KiB and the CU's vector-memory path takes 64 bytes per cycle: the row stores of the first
+        query block are sprinkled through the arithmetic of the second (back to back they cost ~85 cycles each with all four
+        waves storing at once), those of the second run under the MFMAs that zero O and the L arithmetic that is left."""
         e = self.e
         t = [V(x) for x in V_T]
         e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global; O^T := 0"))
-        e(self.make_desc(S_SQ, S_L, S_LSB, S_LSH, S_B, S_HH))
+        e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH))
         e(I("s_nop", 7))  # last P.V MFMAs -> accumulator reads (the descriptor arithmetic above counts as well)
         l = [t[0], t[3]]
-        m2 = [t[1], t[4]]
-        inv = [t[2], t[5]]
+        m2 = [t[1], t[5]]
+        inv = [t[2], t[4]]    # (even registers: they are read as the low word of an aligned 64-bit operand below)
         for qb in range(2):   # register 0 of the row-sum accumulator is the lane's own complete row sum (both lane halves)
             e(I("v_mov_b32", l[qb], V(V_LACC[qb])))
         for qb in range(2):
@@ -906,12 +951,7 @@ class Gen:
             e(I("v_fma_f32", l[qb], -l[qb], inv[qb], 1.0), I("v_add_f32", m2[qb], m2[qb], V(V_MSV[qb])))
         for qb in range(2):
             e(I("v_fma_f32", inv[qb], l[qb], inv[qb], inv[qb]), I(self.cvt, m2[qb], m2[qb], m2[qb]))
-        # L store (lanes 0..31), in the I/O dtype
-        e(I("s_lshr_b64", EXEC, EXEC, 32))
-        for qb in range(2):
-            e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), I("buffer_store_short", m2[qb], V(V_L2), S_SQ, S_T[0], offen=1))
-        e(I("s_mov_b64", EXEC, -1))
-        e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH))
+        e(self.stamp_async(0))
         # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row i, chunk 4 db + g4, +8 h); one query block at a time.
         # (S[0] already holds the next job's first scores and v[128:191] its K(1): rows and temporaries are score buffer 1,
         # whose P was consumed by the job's last P.V.)  A batch = the four 8-byte groups of one 32-column block; the stages
@@ -930,13 +970,45 @@ class Gen:
                         out.append(lists[k][idx[k]])
                         idx[k] += 1
             return out
+
+        def sprinkle(body, extras):
+            """`extras` (instruction groups) spread evenly through `body`"""
+            out, n = [], len(extras)
+            for k, ins in enumerate(body):
+                out.append(ins)
+                j0, j1 = (k * n) // len(body), ((k + 1) * n) // len(body)
+                for j in range(j0, j1):
+                    out += extras[j]
+            return out
+
+        def row_stores(qb):
+            """[[instructions of one row store]] of query block qb (its rows are back in `rows`)"""
+            out = [[I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2),
+                    I("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, S_T[0], offen=1)]]
+            for k in range(1, 8):
+                out.append([I("s_add_u32", S_T[0], S_T[0], S_T[1]), I("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0], offen=1)])
+            return out
+
+        def read_back():
+            out = []
+            for k in range(8):   # whole rows: row 4 k + a
+                if k & 3:
+                    out.append(I("v_xor_b32", addr2, V(V_ER), (k & 3) << 4))
+                    src_a = addr2
+                else:
+                    src_a = V(V_ER)
+                out.append(I("ds_read_b128", rows[k], src_a, offset=1024 * k))
+            return out
+
         for qb in range(2):
             stages = []  # per batch: [reads, muls + address, packs, writes]
             for db in range(4):
                 tm, ad = tset[db & 1], aset[db & 1]
                 src = A_O(qb, db)
                 rd = [I("v_accvgpr_read_b32", tm[k], src.sub(k)) for k in range(16)]
-                mu = [I("v_mul_f32", tm[k], tm[k], inv[qb]) for k in range(16)]
+                # (packed fp32 multiplies: half the instructions; beside an MFMA they would cost ~50 cycles each, here the
+                # matrix pipe is idle and every VALU instruction takes the same ~5.8 cycles at one wave per SIMD)
+                mu = [I("v_pk_mul_f32", V(tm[k].idx, 2), V(tm[k].idx, 2), V(inv[qb].idx, 2), op_sel_hi=(1, 0)) for k in range(0, 16, 2)]
                 ax = [I("v_xor_b32", ad[g4], 4 * db + g4, V(V_ESW)) for g4 in range(4)]
                 al = [I("v_lshl_add_u32", ad[g4], ad[g4], 4, V(V_EW)) for g4 in range(4)]
                 cv = []
@@ -945,35 +1017,37 @@ class Gen:
                 wr = [I("ds_write_b64", ad[g4], V(tm[4 * g4].idx, 2)) for g4 in range(4)]
                 stages.append((rd, weave(mu, ax), weave(cv, al), wr))
             # software pipeline over the four batches (two register sets): batch b + 1 is read while batch b is scaled, ...
-            e(stages[0][0])
-            e(weave(stages[0][1], stages[1][0]))
-            e(stages[0][2], stages[0][3])
-            e(weave(stages[1][1], stages[2][0]))
-            e(stages[1][2], stages[1][3])
-            e(weave(stages[2][1], stages[3][0]))
-            e(stages[2][2], stages[2][3])
-            e(stages[3][1], stages[3][2], stages[3][3])
-            # read back whole rows: row 4 k + a
-            for k in range(8):
-                if k & 3:
-                    e(I("v_xor_b32", addr2, V(V_ER), (k & 3) << 4))
-                    src_a = addr2
-                else:
-                    src_a = V(V_ER)
-                e(I("ds_read_b128", rows[k], src_a, offset=1024 * k))
-            e(I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2))
-            for k in range(8):
-                e(waitcnt(lgkmcnt=7 - k))
-                e(I("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0], offen=1))
-                if k < 7:
-                    e(I("s_add_u32", S_T[0], S_T[0], S_T[1]))
+            head = stages[0][0] + weave(stages[0][1], stages[1][0]) + stages[0][2] + stages[0][3]
+            tail = weave(stages[1][1], stages[2][0]) + stages[1][2] + stages[1][3] + weave(stages[2][1], stages[3][0]) + \
+                stages[2][2] + stages[2][3] + stages[3][1] + stages[3][2] + stages[3][3]
+            e(head)
+            if qb == 1:
+                e(self.stamp_async(2))
+                # the first block's rows have been on their way back from LDS since before this block started (four of this
+                # block's writes are younger): wait for them once, then one row store every ~25 instructions
+                e(waitcnt(lgkmcnt=4))
+                e(sprinkle(tail, row_stores(0)))
+            else:
+                e(tail)
+            e(read_back())
+            e(self.stamp_async(1 if qb == 0 else 3))
         # O^T := 0 and row sums := 0 for the next job; O on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
-        z = V(V_T[2], 4)
+        z = V(SBUF[1] + 32, 4)    # (the second block's temporaries: free again)
         e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
         e([I("v_mov_b32", z.sub(k), 0) for k in range(4)], I("s_nop", 1))
         for qb in range(2):
             for db in range(4):
                 e(I(self.mfma, A_O(qb, db), z, z, 0))
+        e(self.stamp_async(4))
+        e(waitcnt(lgkmcnt=0))
+        e([x for grp in row_stores(1) for x in grp])
+        e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the descriptor arithmetic below: it uses the stamp registers)
+        # L store (lanes 0..31), in the I/O dtype: behind the row stores (they hold the vector-memory path for a while)
+        e(self.make_desc(S_SQ, S_L, S_LSB, S_LSH, S_B, S_HH))
+        e(I("s_lshr_b64", EXEC, EXEC, 32))
+        for qb in range(2):
+            e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), I("buffer_store_short", m2[qb], V(V_L2), S_SQ, S_T[0], offen=1))
+        e(I("s_mov_b64", EXEC, -1))
 
     # ------------------------------------------------------------------ the whole kernel
     def build(self):
@@ -1001,7 +1075,7 @@ class Gen:
         e(self.q_reads(), self.k_reads(0))
         # step -1 (buffers as t4 = 3): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(2), K(3)
         e(self.step(3, with_qk=True, cur=False, with_pv=False, nxt_init=True, masks=(0, (S_NT, 4)) if self.causal else None))
-        e(self.stamp(2), self.stamp_flush(), self.stamp_acc(3))
+        e(self.stamp(2), self.stamp_flush(), self.stamp_acc(3), self.stamp_job(3))
         # ---- job loop
         e(label(l_job))
         e(I("s_lshr_b32", S_LOOP, S_NT, 2), I("s_sub_u32", S_LOOP, S_LOOP, 1),
@@ -1012,7 +1086,7 @@ class Gen:
             e(self.step(t4, steady=True, masks=(0, (S_LOOP, 1)) if self.causal and t4 == 3 else None))
         e(I("s_sub_u32", S_LOOP, S_LOOP, 1), I("s_cmp_lg_u32", S_LOOP, 0), I("s_cbranch_scc1", Label(l_loop)))
         e(label(l_seam))
-        e(self.stamp(3), self.stamp_acc(2), self.stamp_flush())
+        e(self.stamp(3), self.stamp_acc(2), self.stamp_flush(), self.stamp_job(0))
         # ---- the job's last four tiles: the next job's K / V / Q stream in, its first QK^T and softmax start run here
         self.k_advance()
         cm = self.causal
@@ -1049,14 +1123,14 @@ class Gen:
                     kw.update(nxt_init=True, a_pre=[I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)])
                 e(self.stamp(16 + st))
                 e(self.step(st, early=early, pre=pre, **kw))
-        e(self.stamp(4))
+        e(self.stamp(4), self.stamp_job(1))
         self.k_epilogue()
         e(self.stamp(5))
         e(I("s_cmp_lg_u32", S_FINAL, 0), I("s_cbranch_scc1", Label(l_end)))
         self.k_promote()
-        e(self.stamp(0), self.stamp_acc(3))
+        e(self.stamp(0), self.stamp_acc(3), self.stamp_job(2))
         e(I("s_branch", Label(l_job)))
-        e(label(l_end), waitcnt(vmcnt=0), self.stamp(7, real=True), self.stamp(9), I("s_endpgm"))
+        e(label(l_end), self.stamp_job(2), self.stamp_job_flush(), waitcnt(vmcnt=0), self.stamp(7, real=True), self.stamp(9), I("s_endpgm"))
         for blk in self.ool:
             e(blk)
         from .check import check_branch_targets, fix

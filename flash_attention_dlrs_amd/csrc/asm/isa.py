@@ -164,6 +164,8 @@ class Inst:
                 elif k in ("offen", "lds", "glc", "sc0", "sc1", "nt"):
                     if v:
                         s += f" {k}"
+                elif k == "op_sel_hi":   # VOP3P: which half of each source feeds the HIGH result ([1,0]: src1's low word twice)
+                    s += " op_sel_hi:[" + ",".join(str(int(x)) for x in v) + "]"
                 elif k == "off":  # global_* with no saddr
                     pass
                 else:

@@ -13,7 +13,7 @@ from .fa2_a64_gen import module_text
 
 
 class MB:
-    def __init__(self, name, fillers, agpr_c=True, chain=False):
+    def __init__(self, name, fillers, agpr_c=True, chain=False, mfma=True):
         self.name = name
         self.prog = []
         e = self.prog.append
@@ -50,7 +50,8 @@ class MB:
                 acc = A(0, 16) if agpr_c else V(0, 16)
             else:
                 acc = A(16 * u, 16) if agpr_c else V(16 * (u % 4), 16)
-            e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
+            if mfma:
+                e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
             for f in fillers(u):
                 e(f)
         e(I("s_sub_u32", S(16), S(16), 1))
@@ -112,6 +113,17 @@ def cases():
     }
     for nm, pat in pats.items():
         out.append(MB(f"mb_{nm}", (lambda u, pat=pat: [f(u, k) for k, f in enumerate(pat)])))
+    # no MFMA at all (the epilogue's regime): cycles per group of 8 instructions -> / 8 = cycles per instruction
+    ACR = lambda u, k: I("v_accvgpr_read_b32", V(r(u, k)), A(16 * u + k))
+    MUL = lambda u, k: I("v_mul_f32", V(r(u, k)), V(r(u, k)), V(203))
+    XOR = lambda u, k: I("v_xor_b32", V(r(u, k)), 4 + k, V(200))
+    LSA = lambda u, k: I("v_lshl_add_u32", V(r(u, k)), V(r(u, k)), 4, V(201))
+    DSW = lambda u, k: I("ds_write_b64", V(201), V(64 + 2 * ((8 * u + k) % 16), 2), offset=1024 * ((8 * u + k) % 16))
+    solo = {"acr8": [ACR] * 8, "mul8": [MUL] * 8, "cvt8": [CVT] * 8, "xor8": [XOR] * 8, "lsa8": [LSA] * 8, "dsw8": [DSW] * 8,
+            "fma8": [FMA] * 8, "exp8": [EXP] * 8, "acr_mul": [ACR, MUL] * 4, "mul_cvt": [MUL, CVT] * 4, "pk8": [PKA] * 8,
+            "dsr8": [DSR] * 8, "mix": [ACR, MUL, CVT, XOR, ACR, MUL, LSA, DSW]}
+    for nm, pat in solo.items():
+        out.append(MB(f"mb_solo_{nm}", (lambda u, pat=pat: [f(u, k) for k, f in enumerate(pat)]), mfma=False))
     # alternating gaps: even gaps carry the exps, odd gaps the plain VALU
     def alt(u):
         if u & 1:
