@@ -68,7 +68,7 @@ out["seam_steps_cyc"] = [float((d[..., 17] - d[..., 16]).median()), float((d[...
 pts = [d[..., 4], d[..., 13], d[..., 14], d[..., 15], d[..., 20], d[..., 21], d[..., 5]]
 out["epilogue_parts_cyc"] = [float((b - a).median()) for a, b in zip(pts[:-1], pts[1:])]
 if "lite" in os.environ.get("FA2_A64_KERNEL", ""):   # sums over all jobs of a workgroup: steady loops, seam bodies, epilogues, first fill
-    out["all_jobs_cyc"] = {nm: float(lo[:, 0, k].double().median()) for nm, k in (("steady", 10), ("seam", 11), ("epilogue", 12), ("fill", 22))}
+    out["all_jobs_cyc"] = {nm: float(lo[:, 0, k].double().median()) for nm, k in (("steady", 10), ("seam", 11), ("epilogue", 12))}
 real = (d[..., 7] - d[..., 6]).median().item()  # 100 MHz ticks
 out["clock_ghz"] = round(float(seg["kernel"].median()) / real / 10.0, 3) if real > 0 else None
 out["job_cyc"] = float((d[..., 5] - d[..., 0]).median())

@@ -334,6 +334,13 @@ class Workgroup:
     def x_s_cselect_b32(self, w, i):
         w.wr_s(i.ops[0], w.rd_s(i.ops[1]) if w.scc else w.rd_s(i.ops[2]))
 
+    def x_s_cselect_b64(self, w, i):
+        def rd64(o):   # (an inline integer constant is sign-extended to 64 bits)
+            if isinstance(o, int) and not isinstance(o, bool):
+                return o & 0xFFFFFFFFFFFFFFFF
+            return w.rd_s(o)
+        w.wr_s(i.ops[0], rd64(i.ops[1]) if w.scc else rd64(i.ops[2]))
+
     def _scmp(self, w, i, f, signed=False):
         a, b = w.rd_s(i.ops[0]) & 0xFFFFFFFF, w.rd_s(i.ops[1]) & 0xFFFFFFFF
         if signed:
@@ -503,7 +510,11 @@ class Workgroup:
     def x_v_cndmask_b32(self, w, i):
         sel = w.rd_s(i.ops[3])
         bits = np.array([(sel >> l) & 1 for l in range(64)], bool)
-        w.wr_v(i.ops[0], np.where(bits, w.rd_v(i.ops[2]), w.rd_v(i.ops[1])))
+
+        def src(o):   # (VOP3 form: a neg modifier flips the sign bit)
+            x = w.rd_v(o)
+            return x ^ np.uint32(0x80000000) if isinstance(o, Reg) and o.neg else x
+        w.wr_v(i.ops[0], np.where(bits, src(i.ops[2]), src(i.ops[1])))
 
     def _vcmp(self, w, i, f, kind):
         if kind == "f":

@@ -53,7 +53,9 @@ V_ESW = 223               # epilogue swizzle term swz(i)
 V_ER = 224                # epilogue LDS read base
 V_EO = 225                # epilogue global store lane offset (os_n)
 V_L2 = 226                # L store lane offset
-V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), accumulators [4] (228..231)
+V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), accumulators [3] (228..230)
+V_NINF = 231              # causal: -inf (a literal would be the second constant-bus operand beside VCC)
+NINF = V(V_NINF)
 V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
 V_LSV = (234, 235)        # scratch (Q prefetch experiments)
 V_MSV = (236, 237)        # running maximum of the finished job
@@ -62,7 +64,8 @@ V_LACC = (248, 252)       # row-sum accumulators of the two query blocks (4 regi
 V_DQE, V_DQO = 240, 241   # LDS-DMA per-lane source offsets of the Q rows (row stride qs_n; even / odd 8-row group)
 V_QRE, V_QRO = 242, 243   # Q row-read lane bases in the wave's slice (even / odd k-step)
 V_IMH = 238               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
-V_NINF = 239              # causal: -inf
+V_PM = (200, 201, 202, 203, 220, 235, 221, 239)   # causal: AND masks of the eight packed P registers of a triangle group (221 =
+#                           V_LANE, dead after the set-up)
 
 
 # AGPRs
@@ -191,8 +194,8 @@ class Gen:
             return []
         t = S(S_T[0].idx, 2)
         tmp = V(V_T[9])
-        return [I("s_memtime", t), waitcnt(lgkmcnt=0), I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)),
-                I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp), I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
+        acc = [I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)), I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp)] if k < 3 else []
+        return [I("s_memtime", t), waitcnt(lgkmcnt=0)] + acc + [I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
 
     def stamp_job(self, k):
         """lite diagnostic builds: acc[k] += cycles since the previous stamp_job, summed over ALL jobs of the workgroup
@@ -201,14 +204,14 @@ class Gen:
             return []
         t = S(S_T[0].idx, 2)
         tmp = V(V_T[9])
-        return [I("s_memtime", t), waitcnt(lgkmcnt=0), I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)),
-                I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp), I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
+        acc = [I("v_sub_u32", tmp, t.sub(0), V(V_ST_LAST)), I("v_add_u32", V(V_ST_ACC + k), V(V_ST_ACC + k), tmp)] if k < 3 else []
+        return [I("s_memtime", t), waitcnt(lgkmcnt=0)] + acc + [I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
 
     def stamp_job_flush(self):
         if not self.stamps or "lite" not in self.abl:
             return []
         out = [I("v_mov_b32", V(V_T[7]), 0)]
-        for k, slot in enumerate((10, 11, 12, 22)):
+        for k, slot in enumerate((10, 11, 12)):
             out += [I("global_store_dword", V(V_T[7]), V(V_ST_ACC + k), S_DBG, offset=8 * slot)]
         return out
 
@@ -216,7 +219,7 @@ class Gen:
         if not self.stamps or "lite" in self.abl:
             return []
         out = [I("v_mov_b32", V(V_T[7]), 0)]
-        for k in range(4):
+        for k in range(3):
             out += [I("global_store_dword", V(V_T[7]), V(V_ST_ACC + k), S_DBG, offset=8 * (10 + k)),
                     I("v_mov_b32", V(V_ST_ACC + k), 0)]
         return out
@@ -330,7 +333,7 @@ class Gen:
             e(I("s_lshl_b32", S_T[0], S_WGID, 2), I("s_add_u32", S_T[0], S_T[0], S_WAVE), I("s_mul_i32", S_T[0], S_T[0], 8 * NSLOT),
               I("s_add_u32", S_DBG.sub(0), S_DBG.sub(0), S_T[0]), I("s_addc_u32", S_DBG.sub(1), S_DBG.sub(1), 0))
             e(self.stamp(6, real=True), self.stamp(8))
-            e([I("v_mov_b32", V(V_ST_ACC + k), 0) for k in range(4)], I("v_mov_b32", V(V_ST_LAST), 0))
+            e([I("v_mov_b32", V(V_ST_ACC + k), 0) for k in range(3)], I("v_mov_b32", V(V_ST_LAST), 0))
         # ---- row sums on the matrix pipe: the 0 / 1 operand (lanes with (lane & 7) == 4 * ((lane >> 4) & 1) hold ones), accumulators
         one2 = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
         e(comment("row-sum MFMA operand, accumulators, rescale factors"),
@@ -349,7 +352,15 @@ class Gen:
             e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
               I("v_sub_u32", V(V_IMH), t0, t3),   # i - 4 h
-              I("v_mov_b32", V(V_NINF), float("-inf")))
+              I("v_mov_b32", NINF, float("-inf")))
+            e(I("v_mov_b32", V(V_T[4]), 0xFFFF0000), I("v_mov_b32", V(V_T[5]), 0x0000FFFF))
+            # packed P register j of a triangle group holds keys k0 = 2 (j & 1) + 8 (j >> 1) + 4 h and k0 + 1 of query i:
+            # keep both (k0 + 1 <= i), the low one only (k0 == i) or none
+            for j in range(8):
+                k0 = 2 * (j & 1) + 8 * (j >> 1)
+                e(I("v_cmp_ge_i32", VCC, V(V_IMH), k0 + 1), I("v_cndmask_b32", t1, 0, V(V_T[4]), VCC),
+                  I("v_cmp_ge_i32", VCC, V(V_IMH), k0), I("v_cndmask_b32", t2, 0, V(V_T[5]), VCC),
+                  I("v_or_b32", V(V_PM[j]), t1, t2))
 
     # ------------------------------------------------------------------ job decode: S_JOB (+ S_PASS) -> S_NB, S_NHH, S_NQI, S_NNT
     def k_decode_next(self):
@@ -555,6 +566,7 @@ class Gen:
     NB = 40
     PERIOD = 72
     T_END = 104
+    LAZY_TAU = {"ms0": 27, "ms1": 28, "mr": 98, "pm": 99}   # tau of the lazy-masking operations of a diagonal tile (mask_lazy)
 
     def tile_plan(self, init=False, lean=False):
         """placement of the per-tile softmax operations: returns [(tau, kind, payload)] sorted by tau.
@@ -608,6 +620,11 @@ class Gen:
             for part in range(5):
                 t = place(t, (9, 5, 9, 4, 2)[part], "dec", (qb, part)) + 1
             t_dec[qb] = t
+        # (causal diagonal tiles handled lazily -- mask_lazy -- add four small operations at LAZY_TAU: gaps of phase A that are
+        # nearly empty in every tile, so the plan itself does not reserve anything for them)
+        t_d2 = {qb: next(t for t, k, p_ in placed if k == "dec" and p_ == (qb, 2)) for qb in range(2)}
+        lz = self.LAZY_TAU
+        assert lz["mr"] - P < lz["ms0"] < t_d2[0] and lz["mr"] - P < lz["ms1"] < t_d2[1] and lz["pm"] < self.T_END
         # s' = s * c - m, exp2, pack -- element order inside a group is the packing order
         for qb in range(2):
             t_f = t_dec[qb]
@@ -627,6 +644,7 @@ class Gen:
                         tc = place(tc, 5, "cv", (g, j))
                         last_cv.setdefault(g, {})[j] = tc
                     t_e_prev = te
+        assert max(t for t, k, _ in placed if k == "cv") < min(lz["mr"], lz["pm"]), "a pack operation behind the packed-P masking"
         placed.sort(key=lambda x: x[0])
         assert max(t for t, _, _ in placed) < self.T_END, max(t for t, _, _ in placed)
         self._cache[key] = placed
@@ -664,8 +682,11 @@ class Gen:
         between them is the wait state the M0 write needs.  Distinct, two apart, clear of the short row-sum gaps."""
         return (11, 13, 15, 17, 21, 23, 25, 27)[k]
 
-    def tile_op(self, Sb, kind, payload, init):
-        """the instructions of one placed operation, for the tile whose scores live in score buffer Sb"""
+    def tile_op(self, Sb, kind, payload, init, lazy=None):
+        """the instructions of one placed operation, for the tile whose scores live in score buffer Sb.
+        lazy = (jd, cond): the tile is diagonal tile jd of its job (if cond holds) and masked lazily (mask_lazy)"""
+        if kind in ("ms", "mr", "pm"):
+            return self.mask_lazy(Sb, kind, payload, lazy)
         if kind == "mx":
             g, j = payload
             qb, kb = g >> 1, g & 1
@@ -696,7 +717,8 @@ class Gen:
             # rare: raise this query block's running maximum now (every s' = s * c - m of the PREVIOUS tile has been formed:
             # plan order), remember the factor; O and the row sums are scaled at the end of the coming phase B
             t2, t3 = V(V_T[2 + 2 * qb]), V(V_T[3 + 2 * qb])
-            self.ool.append([label(l_fire), I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
+            exact = self.fire_exact(Sb, qb, lazy) if lazy is not None else []
+            self.ool.append([label(l_fire)] + exact + [I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
                              I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
                              I("s_mov_b32", S_FLAG, 1), I("s_branch", Label(l_back))])
             return [I("s_cmp_lg_u64", S_FIRE[qb], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
@@ -713,23 +735,96 @@ class Gen:
         raise KeyError(kind)
 
     def tile_fill(self, Sb, lo, hi, init, masks=None, abl=()):
-        """[(gap - lo, [insts], is_exp)] of the tile's operations with lo <= tau < hi.  masks: causal (jd, cond) -> the masking
-        tests of score group g go in front of its first row-maximum operation"""
+        """[(gap - lo, [insts], is_exp)] of the tile's operations with lo <= tau < hi.  masks: causal (jd, cond): the tile is
+        diagonal tile jd of its job (when cond = (sgpr, value) holds, if given).  A job's first tile (init) gets its scores
+        masked up front -- the tests of score group g go in front of its first row-maximum operation; every other diagonal
+        tile is masked lazily (mask_lazy)"""
         out = []
         seen_mask = set()
-        for t, kind, payload in self.tile_plan(init):
+        jd, cond = (masks + (None,))[:2] if masks is not None else (None, None)
+        lazy = (jd, cond) if masks is not None and not init else None
+        plan = self.tile_plan(init)
+        if lazy is not None:
+            lz = self.LAZY_TAU
+            plan = sorted(plan + [(lz["ms0"], "ms", 0), (lz["ms1"], "ms", 1), (lz["mr"], "mr", None), (lz["pm"], "pm", None)],
+                          key=lambda x: x[0])
+        for t, kind, payload in plan:
             if not (lo <= t < hi):
                 continue
             if ("no_" + kind) in abl or (kind == "dec" and payload[1] >= 3 and "no_fire" in abl):
                 continue   # timing-only ablations (diagnostic build)
-            ins = self.tile_op(Sb, kind, payload, init)
-            if masks is not None and kind == "mx" and payload[1] == 0 and payload[0] not in seen_mask:
+            ins = self.tile_op(Sb, kind, payload, init, lazy)
+            if not ins:
+                continue
+            if masks is not None and init and kind == "mx" and payload[1] == 0 and payload[0] not in seen_mask:
                 seen_mask.add(payload[0])
-                ins = self.mask_tests(Sb, payload[0], *masks) + ins
+                ins = self.mask_tests(Sb, payload[0], jd, cond) + ins
             out.append((t - lo, ins, kind == "e"))
         return out
 
     # ------------------------------------------------------------------ causal masks
+    def score_mask_ops(self, Y, g):
+        """the wave ON the diagonal (w == jd): -inf into the scores of group g = 2 qb + kb whose key lies behind the query.
+        (qb0, kb0) and (qb1, kb1) get the triangle, (qb0, kb1) is masked entirely, (qb1, kb0) not at all.  Register r of a
+        group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i"""
+        if g in (0, 3):
+            out = []
+            for r in range(16):
+                key = (r & 3) + 8 * (r >> 2)
+                out += [I("v_cmp_ge_i32", VCC, V(V_IMH), key), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
+            return out
+        if g == 1:
+            return [I("v_mov_b32", V(Y + 16 + r), NINF) for r in range(16)]
+        return []
+
+    def mask_lazy(self, Sb, kind, payload, lazy):
+        """Diagonal tiles other than a job's first are not masked before the softmax: the row maxima are taken over all 64 keys
+        (a masked key can only RAISE a maximum: harmless unless it fires the deferred-maximum rescale, and that path --
+        fire_exact -- masks the scores exactly and takes the maxima again), and
+          'pm'  the wave on the diagonal clears the masked entries of the PACKED P (24 instructions out of line instead of 80
+                on the fp32 scores: 8 AND masks per triangle group from the set-up, 8 zero moves for the hidden group);
+          'ms'  waves below the diagonal (the whole tile is hidden from them) swap +inf in for the running maximum of the
+                query block, so that every exp2(s c - m) is 0 and nothing fires;  'mr' puts the maximum back.
+        Both are in line, wave-uniform selects instead of branches (a taken branch costs ~25 cycles at one wave per SIMD)."""
+        jd, cond = lazy
+        if kind == "pm":
+            l_pm, l_back = self.lab("pmask"), self.lab("pmask_back")
+            blk = [label(l_pm)]
+            if cond is not None:
+                blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_back))]
+            for g in (0, 3):
+                blk += [I("v_and_b32", V(Sb + 16 * g + j), V(Sb + 16 * g + j), V(V_PM[j])) for j in range(8)]
+            blk += [I("v_mov_b32", V(Sb + 16 + j), 0) for j in range(8)]
+            self.ool.append(blk + [I("s_branch", Label(l_back))])
+            return [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_pm)), label(l_back)]
+        if jd == 0:
+            return []      # no wave lies below diagonal tile 0
+        assert cond is None
+        sel = [I("s_cmp_ge_u32", S_WAVE, jd), I("s_cselect_b64", VCC, -1, 0)]   # VCC: the tile is (partly) visible to this wave
+        if kind == "ms":
+            qb = payload
+            return sel + [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])), I("v_cndmask_b32", V(V_MC[qb]), -NINF, V(V_MC[qb]), VCC)]
+        return sel + [I("v_cndmask_b32", V(V_MC[qb]), V(V_MSV[qb]), V(V_MC[qb]), VCC) for qb in range(2)]
+
+    def fire_exact(self, Sb, qb, lazy):
+        """head of the rare rescale path of a lazily masked diagonal tile: on the wave that sits on the diagonal the row maxima
+        were taken over masked keys too -- mask this query block's scores now and take the maxima again (then the plain path
+        decides with the exact maximum; the packed-P masking later is a no-op on the -inf entries)"""
+        jd, cond = lazy
+        l_plain = self.lab("fire_plain")
+        a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
+        blk = []
+        if cond is not None:
+            blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_plain))]
+        blk += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc0", Label(l_plain))]
+        for g, mx in ((2 * qb, a), (2 * qb + 1, b)):
+            blk += self.score_mask_ops(Sb, g)
+            y = lambda r: V(Sb + 16 * g + r)
+            blk += [I("v_max3_f32", mx, y(0), y(1), y(2))] + [I("v_max3_f32", mx, mx, y(2 * j + 1), y(2 * j + 2)) for j in range(1, 7)] + \
+                [I("v_max_f32", mx, mx, y(15))]
+        blk += [I("v_max_f32", a, a, b), I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b), label(l_plain)]
+        return blk
+
     def mask_tests(self, Y, g, jd, cond=None):
         """causal: the tile whose softmax starts is diagonal tile jd (0..3) of its job: keys 64 jd .. 64 jd + 63 of the 256-key
         diagonal span against this wave's rows 64 w .. 64 w + 63.  w > jd: nothing; w == jd: score groups (qb0, kb0) and
@@ -740,20 +835,13 @@ class Gen:
         (check.check_branch_targets verifies it on the built program)."""
         l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
         tests = []
-        ninf = V(V_NINF)
-        eq_ops = []
-        if g in (0, 3):
-            for r in range(16):
-                key = (r & 3) + 8 * (r >> 2)
-                eq_ops += [I("v_cmp_lt_i32", VCC, V(V_IMH), key), I("v_cndmask_b32", V(Y + 16 * g + r), V(Y + 16 * g + r), ninf, VCC)]
-        elif g == 1:
-            eq_ops = [I("v_mov_b32", V(Y + 16 + r), ninf) for r in range(16)]
+        eq_ops = self.score_mask_ops(Y, g)
         if eq_ops:
             tests += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
             self.ool.append([label(l_eq)] + eq_ops + [I("s_branch", Label(l_back))])
         if jd > 0:
             tests += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
-            self.ool.append([label(l_lt)] + [I("v_mov_b32", V(Y + 16 * g + r), ninf) for r in range(16)] +
+            self.ool.append([label(l_lt)] + [I("v_mov_b32", V(Y + 16 * g + r), NINF) for r in range(16)] +
                             [I("s_branch", Label(l_back))])
         if cond is None:
             return tests + [label(l_back)]
@@ -775,7 +863,7 @@ class Gen:
                 out += ins
         return out
 
-    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=()):
+    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=(), cur_masks=None, extra=()):
         """A(t), t4 = t & 3: QK^T(t+1) -> S[1-p]  ||  V(t) reads from VB[t % R]  ||  the late softmax operations of tile t (on S[p])
         ||  the early ones of tile t+1 (on S[1-p])"""
         p = t4 & 1
@@ -789,11 +877,13 @@ class Gen:
                 for k, ins in enumerate(self.v_reads(t4 % self.R)):
                     add(self.a_vread_gap(k), 0, [ins])
             if "nofinish" not in abl:
-                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False, abl=abl):
+                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False, cur_masks, abl=abl):
                     add(k, 1 if is_exp else 2, ins)
         if nxt and "nostart" not in abl:
             for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks, abl=abl):
                 add(k, 1 if is_exp else 2, ins)
+        for g, ins in extra:
+            add(g, 2, ins)
         for g, setup, load in dma:   # LDS-DMA pieces riding in this phase (the seam's Q rows): set-up ends gap g - 1, load opens gap g
             add(g - 1, 3, setup)
             add(g, 0, [load])
@@ -909,7 +999,7 @@ class Gen:
 
     def step(self, t4, a_pre=(), **kw):
         """one tile step, t4 = t & 3"""
-        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady", "dma")}
+        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady", "dma", "cur_masks", "extra")}
         kb = {k: v for k, v in kw.items() if k in ("with_pv", "nxt", "nxt_init", "with_kread", "with_dma", "steady", "pre", "early", "late",
                                                    "own_gaps")}
         if kw.get("masks") is not None:   # the masking tests of a score group sit in front of its first row-maximum operation
@@ -1097,7 +1187,7 @@ class Gen:
             sk, sv = 4 - self.dk, 4 - self.dv      # seam step whose phase B streams the next job's first K / V tile
             qs_setup, qs_pieces = self.q_stage(S_NB, S_NHH, S_NQI)
             for st in range(4):
-                kw = dict(masks=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None)
+                kw = dict(masks=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None, cur_masks=(st,) if cm else None)
                 early, pre = [], []
                 if st == 0:
                     # the next job's Q rows start their way into the wave's LDS slice: sixteen pieces, never more than one
@@ -1120,7 +1210,11 @@ class Gen:
                 if st == 3:
                     # the job's last tile: its running maxima are put aside for the epilogue before the next job's first
                     # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
-                    kw.update(nxt_init=True, a_pre=[I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)])
+                    save = [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
+                    if cm:   # (behind the diagonal tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
+                        kw.update(nxt_init=True, extra=[(self.LAZY_TAU["mr"] - self.PERIOD + 1, save)])
+                    else:
+                        kw.update(nxt_init=True, a_pre=save)
                 e(self.stamp(16 + st))
                 e(self.step(st, early=early, pre=pre, **kw))
         e(self.stamp(4), self.stamp_job(1))
@@ -1200,10 +1294,6 @@ def main(argv=None):
         g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite", stamps=True, abl=("lite",))
         g.build()
         gens.append(g)
-        for nd in (0, 8, 12, 16):   # placement experiments of the V reads (correct kernels)
-            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_vr{nd}", stamps=True, abl=("lite",), vread_double=nd)
-            g.build()
-            gens.append(g)
         for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
             g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
             g.build()

@@ -223,7 +223,7 @@ class Inst:
             if op in ("s_add_u32", "s_sub_u32", "s_addc_u32", "s_and_b32", "s_or_b32", "s_lshl_b32", "s_lshr_b32", "s_and_b64",
                       "s_or_b64", "s_lshr_b64", "s_min_u32", "s_max_u32", "s_sub_i32", "s_add_i32", "s_andn2_b64", "s_xor_b32", "s_bfe_u32"):
                 d = d + [("scc", 0)]
-            if op in ("s_addc_u32", "s_cselect_b32"):
+            if op in ("s_addc_u32", "s_cselect_b32", "s_cselect_b64"):
                 u = u + [("scc", 0)]
             return d, u
         raise NotImplementedError(op)

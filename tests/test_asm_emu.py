@@ -82,6 +82,27 @@ def test_emulated_kernel_frequent_rescales_across_jobs(oracle):
     assert not np.isnan(O).any() and np.abs(O - O_ref).max() <= O_TOL["bf16"]
 
 
+@pytest.mark.parametrize("dtype,thr", [("bf16", None), ("f16", None), ("bf16", 8.0)])
+def test_emulated_causal_diagonal_with_large_masked_scores(oracle, dtype, thr):
+    """the lazily masked diagonal tiles: keys a few positions AHEAD of their query carry scores far above every visible one
+    (s = 40 .. 160 log2 units).  The row maxima are taken over them; that must neither leak into m (the firing path masks
+    exactly and takes the maxima again) nor into P (the packed-P masking), on the wave that sits on the diagonal, on the waves
+    below it (running maximum swapped for +inf) and in the steady loop's last trip (diagonal tile 0 of a longer job)."""
+    rng = np.random.default_rng(11)
+    B, H, N = 1, 2, 768
+    Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) * 0.5 for _ in range(3))
+    for q, ahead, gain in ((5, 3, 2.0), (40, 20, 4.0), (100, 60, 8.0), (300, 1, 6.0), (517, 50, 3.0), (600, 100, 5.0), (767 - 64, 63, 8.0)):
+        K[:, :, q + ahead] = gain * Q[:, :, q]        # masked for row q; visible (and large) only for rows >= q + ahead
+    _, p = prog(dtype, True)
+    kw = dict(thr_override=thr) if thr is not None else {}
+    O, L, _ = harness.run(p, Q, K, V, dtype=dtype, causal=True, nwg=1, **kw)
+    rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
+    O_ref, L_ref = oracle.forward(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=True, B_r=64, B_c=64)
+    assert not np.isnan(O).any() and np.abs(O - O_ref).max() <= O_TOL[dtype], np.abs(O - O_ref).max()
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(L_ref).max())) - (7 if dtype == "bf16" else 10))
+    assert np.abs(L - L_ref.reshape(L.shape)).max() <= 1.01 * ulp
+
+
 def test_emulated_kernel_rescale_path(oracle):
     _run(oracle, "bf16", False, 1, 1, 512, spike=True, seed=2)
 
