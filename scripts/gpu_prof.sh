@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 ARGS="${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline --no-extras}"
 echo "=== stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 2; }
