@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where does the static tile table switch between the 128-row kernel (mfma16d_w4), the persistent 256-row kernel
-(mfma16h) and the key-split kernel (mfma16k)?  Eager microseconds per launch (bf16) over grids of 128..1024 tiles.
+"""Where does the static tile table switch between the 128-row kernel (mfma16d_w4), the persistent 256-row kernels
+(mfma16h, and for d = 128 the generated assembly kernel a64) and the key-split kernel (mfma16k)?  Eager microseconds per launch (bf16) over grids of 128..1024 tiles.
 
     python benchmarks/mid_grid.py
 """
@@ -31,7 +31,8 @@ def t(fn, it=30):
     return best
 
 
-for d in (128, 64):
+ONLY_D = [int(x) for x in os.environ.get("MID_GRID_D", "128,64").split(",")]
+for d in ONLY_D:
     for causal in (False, True):
         for N in (1024, 2048, 4096, 8192):
             for BH in (8, 12, 16, 24, 32, 48, 64):
@@ -40,7 +41,8 @@ for d in (128, 64):
                     continue
                 Q, K, V = (torch.randn(1, BH, N, d, device=dev).to(torch.bfloat16) for _ in range(3))
                 r = {"d": d, "causal": causal, "N": N, "BH": BH, "wg256": wg256}
-                for v in ("auto", "mfma16d_w4", "mfma16h", "mfma16k"):
+                cands = ("mfma16d_w4", "mfma16h", "mfma16k") + (("a64",) if d == 128 and N % 256 == 0 else ())
+                for v in ("auto",) + cands:
                     r[v] = round(t(lambda: flash_attention_forward(Q, K, V, dev, causal=causal, variant=v)), 1)
-                r["best"] = min(("mfma16d_w4", "mfma16h", "mfma16k"), key=lambda k: r[k])
+                r["best"] = min(cands, key=lambda k: r[k])
                 print(json.dumps(r), flush=True)

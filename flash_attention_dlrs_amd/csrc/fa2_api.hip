@@ -65,6 +65,14 @@ int pick_variant(const Fa2Problem &p) {
                             (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
         if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
+        // d = 128, N a multiple of 256: the generated assembly kernel A64 (4 waves x 64 rows, one wave per SIMD, O / Q / V^T in
+        // the accumulator file) wins from 64 jobs of 256 rows on -- a quarter of the CUs busy -- non-causal, and causal from
+        // 192 jobs (or 96 when a job has at least eight key tiles); below that the key-split kernels keep more CUs busy.
+        // benchmarks/mid_grid.py, 48 shapes, bf16, d = 128, profiles/r02/mid_grid_a64.jsonl: against the best of
+        // MFMA16D_W4 / MFMA16H / MFMA16K it is 4-33 % faster on every shape from those sizes up (the persistent grid also
+        // takes job counts that are not a multiple of the CU count better: 1.5 jobs per CU 180 vs 213 us); on the same
+        // MI355X against MFMA16H: c3 causal +15-19 %, c3 shape non-causal +15-17 %.
+        if (fa2_a64_supports(p) && (p.causal ? (wg256 >= 192 || (wg256 >= 96 && p.N >= 2048)) : wg256 >= 64)) return FA2_VARIANT_A64;
         // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and
         // every workgroup walks its key tiles in sequence -- latency-bound.  MFMA16K splits the keys of a tile among
         // wave groups of the same workgroup (no workspace): benchmarks/tiny_grid.py, HIP-graph replay, fp16:
@@ -95,11 +103,6 @@ int pick_variant(const Fa2Problem &p) {
         } else {
             if (wg256 < 160 || !even) return FA2_VARIANT_MFMA16D_W4;
         }
-        // d = 128, N a multiple of 256, enough 256-row jobs to fill the CUs: the generated assembly kernel A64 (4 waves x 64
-        // rows, one wave per SIMD, O / Q / V^T in the accumulator file).  Against MFMA16H on the same MI355X (interleaved
-        // rounds, benchmarks/variants.py, profiles/r02/): c3 causal +11 %, c3 shape non-causal +12 %, N = 2048 causal +16 %,
-        // B16 H64 N2048 +15 %, N = 8192 / 16384 causal +9 %.
-        if (fa2_a64_supports(p)) return FA2_VARIANT_A64;
         // 8-wave tiles: MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop).  Against MFMA16D on
         // MI355X (benchmarks/lottery.py, alternating order): non-causal +4.4 % (d = 128, N = 4096), +3.4 % (N = 8192),
         // +9 % (d = 64); causal, once its causal kernels got a translation unit of their own: +4.1 % at the north-star
