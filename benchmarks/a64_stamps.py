@@ -69,6 +69,14 @@ pts = [d[..., 4], d[..., 13], d[..., 14], d[..., 15], d[..., 20], d[..., 21], d[
 out["epilogue_parts_cyc"] = [float((b - a).median()) for a, b in zip(pts[:-1], pts[1:])]
 if "lite" in os.environ.get("FA2_A64_KERNEL", ""):   # sums over all jobs of a workgroup: steady loops, seam bodies, epilogues, first fill
     out["all_jobs_cyc"] = {nm: float(lo[:, 0, k].double().median()) for nm, k in (("steady", 10), ("seam", 11), ("epilogue", 12))}
+# spread over the workgroups (wave 0): start skew, length, end skew, in ns
+st, en = d[:, 0, 6] * 10.0, d[:, 0, 7] * 10.0     # s_memrealtime ticks (100 MHz, common to the XCDs) -> ns
+q = lambda x: [float(x.min()), float(x.median()), float(x.max())]
+out["wg_start_rel"] = q(st - st.min())
+out["wg_len"] = q(en - st)
+out["wg_end_rel"] = q(en - st.min())
+out["wg_len_by_xcd_us"] = [round(float((en - st)[x::8].mean()) / 1e3, 1) for x in range(8)]   # workgroup id % 8 = XCD
+out["wg_len_spread_in_xcd_us"] = [round(float(((en - st)[x::8].max() - (en - st)[x::8].min())) / 1e3, 1) for x in range(8)]
 real = (d[..., 7] - d[..., 6]).median().item()  # 100 MHz ticks
 out["clock_ghz"] = round(float(seg["kernel"].median()) / real / 10.0, 3) if real > 0 else None
 out["job_cyc"] = float((d[..., 5] - d[..., 0]).median())
