@@ -43,6 +43,8 @@ CONFIGS = {  # BASELINE.json "configs"
     "causal_16k": dict(B=1, H=32, N=16384, d=128, dtype="bf16", causal=True),
     "causal_8k": dict(B=2, H=32, N=8192, d=128, dtype="bf16", causal=True),
     "causal_2k": dict(B=8, H=32, N=2048, d=128, dtype="bf16", causal=True),
+    "ragged_4000": dict(B=4, H=32, N=4000, d=128, dtype="bf16", causal=False),          # N not a multiple of 256: the ragged a64 kernels
+    "ragged_4000_causal": dict(B=4, H=32, N=4000, d=128, dtype="bf16", causal=True),
     "n2048": dict(B=16, H=64, N=2048, d=128, dtype="bf16", causal=False),
     "c3_fp8": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=True),
     "c5_per_gpu": dict(B=16, H=8, N=16384, d=128, dtype="fp8", causal=False),   # BASELINE.json configs[4], one GPU's head shard
@@ -305,6 +307,19 @@ def main():
         torch.cuda.synchronize(dev)
         extras["tflops_inputs_scaled_d^-1/4"] = round(F / (a.elapsed_time(b) / 100 * 1e-3) / 1e12, 2)
         del Q2, K2
+        # (1a) the same shape and inputs WITHOUT the causal mask (BASELINE.json's metric string and the north star's target
+        # name the shape, configs[2] adds the mask: `value` is the masked case, this is the other reading)
+        if c["causal"]:
+            for _ in range(10):
+                flash_attention_forward(Q, K, V, dev, causal=False, variant=variant)
+            torch.cuda.synchronize(dev)
+            a.record()
+            for _ in range(50):
+                flash_attention_forward(Q, K, V, dev, causal=False, variant=variant)
+            b.record()
+            torch.cuda.synchronize(dev)
+            tnc = 2.0 * F / (a.elapsed_time(b) / 50 * 1e-3) / 1e12
+            extras["same_shape_no_mask"] = {"tflops": round(tnc, 2), "pct_of_mfma_peak": round(100 * tnc / peak, 2)}
         # (1b) the backward of the same workload (the reference bench's default mode,
         # src/bench.py:20): D + dQ + dK/dV launches of include/fa2_bwd.h, TFLOP/s at the 2.5 x forward convention
         if c["dtype"] in ("bf16", "fp16", "f32"):

@@ -111,6 +111,7 @@ S_T = tuple(S(88 + k) for k in range(8))  # temporaries s88..s95 (S_T[0] even: u
 S_QROW = (S(96), S(97))          # first row of the wave's query block qb (current job)
 S_DBG = S(98, 2)
 S_KW, S_VW = S(100), S(101)      # 8 * wave * row stride: the wave's row base inside a tile
+S_KT0 = S(86)                    # (= S_PASS, causal only) non-causal ragged: real keys in the job's last 256 = N - 256 (nq - 1)
 S_LG = S(73)                     # decode shifts: lgH | lgG << 8 | lg(G * nunit) << 16 | pow2-mode << 24
 S_FIRE = (S(0, 2), S(2, 2))      # per query block: lanes whose row maximum passed the deferral threshold (s0..s3 are free after the set-up)
 S_X2 = S(82)
@@ -128,17 +129,21 @@ NSLOT = 24
 
 
 class Gen:
-    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4):
+    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
-        self.name = name or f"fa2_fwd_a64_{dtype}_{'c' if causal else 'n'}"
+        self.name = name or f"fa2_fwd_a64_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
+        self.atmp = 0          # (ragged) which of the two address temporaries the next buffer operation takes
+        self.atmp_regs = (V_T[8], V_T[9])
         self.prog: list[Inst] = []
         self.uid = 0
         self.nexp_b = nexp_b
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
+        self.ragged = ragged   # N is not a multiple of 256: range-checked descriptors, every offset in the VGPR operand, masked key tail
+        assert not (ragged and stamps), "the ragged kernels use the stamps' temporaries as address registers"
         self.vread_double = vread_double   # phase-A gaps that carry two V transposed reads (the last read sits in gap 31 - this)
         self.abl = set(abl)    # timing-only ablations of the steady loop (diagnostic builds; results wrong by construction)
         self.R, self.dk, self.dv = ring   # ring depth; K(t + dk) and V(t + dv) are streamed in phase B(t): dk <= R + 1, dv <= R
@@ -247,13 +252,31 @@ class Gen:
                 I("s_add_u32", dst.sub(0), dst.sub(0), lo), I("s_addc_u32", dst.sub(1), dst.sub(1), hi),
                 I("s_mul_i32", lo, idx, stride.sub(1)), I("s_add_u32", dst.sub(1), dst.sub(1), lo)]
 
-    def make_desc(self, rs: Reg, base: Reg, sb: Reg, sh: Reg, b: Reg, hh: Reg):
-        """raw buffer descriptor of the (b, hh) slice of a tensor: base + b * sb + hh * sh (the range check is not used:
-        soffset is unchecked anyway; every address the kernel forms lies inside the tensor, N being a multiple of 256)"""
+    def make_desc(self, rs: Reg, base: Reg, sb: Reg, sh: Reg, b: Reg, hh: Reg, sn=None):
+        """raw buffer descriptor of the (b, hh) slice of a tensor: base + b * sb + hh * sh.  N a multiple of 256: the range check
+        is not used (soffset is unchecked anyway; every address the kernel forms lies inside the tensor).  Ragged kernels:
+        num_records = (N - 1) * sn + 256 bytes of rows (sn: the row stride register; an int: bytes per row of L) -- loads of
+        rows past N come back as zeros, stores to them are dropped; those kernels keep every offset in the VGPR operand"""
         tmp = S(S_T[0].idx, 2)
-        return ([I("s_mov_b64", tmp, base)] + self.mad64(tmp, b, sb) + self.mad64(tmp, hh, sh) +
-                [I("s_mov_b32", rs.sub(0), tmp.sub(0)), I("s_and_b32", rs.sub(1), tmp.sub(1), 0xFFFF),
-                 I("s_mov_b32", rs.sub(2), 0x7FFFFFF0), I("s_mov_b32", rs.sub(3), 0x00020000)])
+        out = ([I("s_mov_b64", tmp, base)] + self.mad64(tmp, b, sb) + self.mad64(tmp, hh, sh) +
+               [I("s_mov_b32", rs.sub(0), tmp.sub(0)), I("s_and_b32", rs.sub(1), tmp.sub(1), 0xFFFF), I("s_mov_b32", rs.sub(3), 0x00020000)])
+        if not self.ragged:
+            return out + [I("s_mov_b32", rs.sub(2), 0x7FFFFFF0)]
+        assert sn is not None
+        if isinstance(sn, int):
+            return out + [I("s_mul_i32", rs.sub(2), S_N, sn)]
+        return out + [I("s_sub_u32", S_T[6], S_N, 1), I("s_mul_i32", S_T[6], S_T[6], sn), I("s_add_u32", rs.sub(2), S_T[6], 256)]
+
+    def buf_op(self, op, data, voff: Reg, rsrc: Reg, soff, **mods):
+        """a buffer operation at byte offset voff (per lane) + soff (scalar).  The scalar operand of the instruction is not
+        range-checked: the ragged kernels add it into an address temporary first (two, taken alternately: a set-up may run
+        ahead of the previous piece's load by one gap).  Returns (set-up instructions, the memory instruction)"""
+        ops = (lambda v, so: (data, v, rsrc, so) if data is not None else (v, rsrc, so))
+        if not self.ragged:
+            return [], I(op, *ops(voff, soff), offen=1, **mods)
+        tmp = V(self.atmp_regs[self.atmp])
+        self.atmp ^= 1
+        return [I("v_add_u32", tmp, soff, voff)], I(op, *ops(tmp, 0), offen=1, **mods)
 
     # ------------------------------------------------------------------ kernel prologue: arguments, lane constants
     def k_setup(self):
@@ -348,6 +371,10 @@ class Gen:
           I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
           I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
+        if self.ragged and not self.causal:
+            e(comment("ragged, non-causal: real keys in a job's last 256; -inf"),
+              I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
+              I("v_mov_b32", NINF, float("-inf")))
         if self.causal:
             e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
@@ -406,7 +433,7 @@ class Gen:
               label(l_p1), I("s_mov_b32", S_NQI, S_UNIT), label(l_pd),
               I("s_add_u32", t[0], S_NQI, 1), I("s_lshl_b32", S_NNT, t[0], 2))
         else:
-            e(I("s_mov_b32", S_NQI, S_UNIT), I("s_lshr_b32", S_NNT, S_N, 6))
+            e(I("s_mov_b32", S_NQI, S_UNIT), I("s_lshl_b32", S_NNT, S_NQ, 2))      # (4 tiles per 256 rows, N rounded up)
 
     def k_advance(self):
         """S_JOB / S_PASS -> the job after the most recently decoded one, decoded into the next-job registers;
@@ -452,9 +479,8 @@ class Gen:
             so = S_T[5]
             out.append(I("s_add_u32", so, base, s32))
         out.append(I("s_add_u32", M0, S_LDSW, lds0 + (0, 1024, 8192, 9216)[piece]))
-        out.append(I("s_nop", 0))
-        out.append(I("buffer_load_dwordx4", vl2 if piece & 1 else vl, rsrc, so, offen=1, lds=1, tag=f"dma {which}{piece}"))
-        return out
+        pre, ld = self.buf_op("buffer_load_dwordx4", None, vl2 if piece & 1 else vl, rsrc, so, lds=1, tag=f"dma {which}{piece}")
+        return out + pre + [I("s_nop", 0), ld]
 
     def dma_tile(self, which, buf):
         out = []
@@ -467,7 +493,7 @@ class Gen:
         """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the K-tile image (16 pieces of 8 rows x
         128 bytes: coalesced, ~25 cycles of issue each; the same rows fetched straight into the MFMA operand layout -- 32 rows x
         32 bytes per instruction -- cost ~210 cycles per load).  Returns (descriptor / offset setup, [pieces])"""
-        setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh)
+        setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh, S_QSN)
         setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
                   I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
                   I("s_lshl_b32", S_T[3], S_QSN, 3),                    # 8 rows
@@ -484,8 +510,8 @@ class Gen:
                     if R < 7:
                         pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
                 pc.append(I("s_add_u32", M0, S_T[4], 2048 * R + 1024 * half))
-                ld = I("buffer_load_dwordx4", V(V_DQO if R & 1 else V_DQE), S_SQ, so, offen=1, lds=1, tag=f"qdma R{R} h{half}")
-                pieces.append((pc, ld))
+                pre, ld = self.buf_op("buffer_load_dwordx4", None, V(V_DQO if R & 1 else V_DQE), S_SQ, so, lds=1, tag=f"qdma R{R} h{half}")
+                pieces.append((pc + pre, ld))
         return setup, pieces
 
     def q_reads(self):
@@ -741,24 +767,31 @@ class Gen:
         tile is masked lazily (mask_lazy)"""
         out = []
         seen_mask = set()
+        tail = masks is not None and masks[0] == "tail"     # non-causal ragged: ("tail", j[, cond]) -- seam tile j may hold keys >= N
+        if tail:
+            masks = masks[1:]
         jd, cond = (masks + (None,))[:2] if masks is not None else (None, None)
         lazy = (jd, cond) if masks is not None and not init else None
         plan = self.tile_plan(init)
         if lazy is not None:
             lz = self.LAZY_TAU
-            plan = sorted(plan + [(lz["ms0"], "ms", 0), (lz["ms1"], "ms", 1), (lz["mr"], "mr", None), (lz["pm"], "pm", None)],
-                          key=lambda x: x[0])
+            plan = sorted(plan + [(lz["ms0"], "ms", 0), (lz["ms1"], "ms", 1), (lz["mr"], "mr", None)] +
+                          ([] if tail else [(lz["pm"], "pm", None)]), key=lambda x: x[0])
         for t, kind, payload in plan:
             if not (lo <= t < hi):
                 continue
             if ("no_" + kind) in abl or (kind == "dec" and payload[1] >= 3 and "no_fire" in abl):
                 continue   # timing-only ablations (diagnostic build)
-            ins = self.tile_op(Sb, kind, payload, init, lazy)
+            if tail:
+                assert not init
+                ins = self.mask_tail(Sb, kind, payload, jd, cond) if kind in ("ms", "mr") else self.tile_op(Sb, kind, payload, init, None)
+            else:
+                ins = self.tile_op(Sb, kind, payload, init, lazy)
             if not ins:
                 continue
-            if masks is not None and init and kind == "mx" and payload[1] == 0 and payload[0] not in seen_mask:
+            if masks is not None and (init or tail) and kind == "mx" and payload[1] == 0 and payload[0] not in seen_mask:
                 seen_mask.add(payload[0])
-                ins = self.mask_tests(Sb, payload[0], jd, cond) + ins
+                ins = (self.mask_tail_tests(Sb, payload[0], jd, cond) if tail else self.mask_tests(Sb, payload[0], jd, cond)) + ins
             out.append((t - lo, ins, kind == "e"))
         return out
 
@@ -805,6 +838,40 @@ class Gen:
             qb = payload
             return sel + [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])), I("v_cndmask_b32", V(V_MC[qb]), -NINF, V(V_MC[qb]), VCC)]
         return sel + [I("v_cndmask_b32", V(V_MC[qb]), V(V_MSV[qb]), V(V_MC[qb]), VCC) for qb in range(2)]
+
+    def mask_tail(self, Sb, kind, payload, j, cond):
+        """non-causal ragged, seam tile j (keys 64 j .. 64 j + 63 of the job's last 256; S_KT0 of them are real): a tile wholly
+        behind N gets +inf for the running maximum like a tile below the causal diagonal (mask_lazy 'ms' / 'mr')"""
+        if j == 0:
+            return []          # at least one key of tile 0 is real
+        assert cond is None
+        sel = [I("s_cmp_gt_i32", S_KT0, 64 * j), I("s_cselect_b64", VCC, -1, 0)]     # VCC: the tile holds a real key
+        if kind == "ms":
+            qb = payload
+            return sel + [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])), I("v_cndmask_b32", V(V_MC[qb]), -NINF, V(V_MC[qb]), VCC)]
+        return sel + [I("v_cndmask_b32", V(V_MC[qb]), V(V_MSV[qb]), V(V_MC[qb]), VCC) for qb in range(2)]
+
+    def mask_tail_tests(self, Y, g, j, cond):
+        """in front of score group g's first row-maximum operation: if some of its 32 keys lie at or behind N (and some key of
+        the tile is real: else mask_tail deals with it), -inf into those scores, out of line.  Register r of a group <-> key
+        (r & 3) + 8 (r >> 2) + 4 h of the group's 32"""
+        kb = g & 1
+        l_m, l_back = self.lab("tail"), self.lab("tail_back")
+        t = V(V_T[6])
+        blk = [label(l_m)]
+        if cond is not None:
+            blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_back))]
+        if j > 0:
+            blk += [I("s_cmp_gt_i32", S_KT0, 64 * j), I("s_cbranch_scc0", Label(l_back))]
+        # T = real keys of this group minus the lane half's offset: register r is kept iff T > (r & 3) + 8 (r >> 2)
+        # (S_X2, the job decode's scratch: the S_T temporaries may be in the middle of a descriptor computation spread over gaps)
+        blk += [I("s_sub_i32", S_X2, S_KT0, 64 * j + 32 * kb), I("v_lshrrev_b32", t, 5, V(V_LANE)), I("v_lshlrev_b32", t, 2, t),
+                I("v_sub_u32", t, S_X2, t)]
+        for r in range(16):
+            blk += [I("v_cmp_gt_i32", VCC, t, (r & 3) + 8 * (r >> 2)), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
+        self.ool.append(blk + [I("s_branch", Label(l_back))])
+        # in line: one compare and an untaken branch while all 32 keys of the group are real
+        return [I("s_cmp_lt_i32", S_KT0, 64 * j + 32 * kb + 32), I("s_cbranch_scc1", Label(l_m)), label(l_back)]
 
     def fire_exact(self, Sb, qb, lazy):
         """head of the rare rescale path of a lazily masked diagonal tile: on the wave that sits on the diagonal the row maxima
@@ -1026,7 +1093,7 @@ class Gen:
         e = self.e
         t = [V(x) for x in V_T]
         e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global; O^T := 0"))
-        e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH))
+        e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH, S_OSN))
         e(I("s_nop", 7))  # last P.V MFMAs -> accumulator reads (the descriptor arithmetic above counts as well)
         l = [t[0], t[3]]
         m2 = [t[1], t[5]]
@@ -1042,6 +1109,7 @@ class Gen:
         for qb in range(2):
             e(I("v_fma_f32", inv[qb], l[qb], inv[qb], inv[qb]), I(self.cvt, m2[qb], m2[qb], m2[qb]))
         e(self.stamp_async(0))
+        self.atmp_regs = (V_T[0], V_T[3])     # (the row sums are consumed: V_T[6..9] are LDS addresses from here on)
         # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row i, chunk 4 db + g4, +8 h); one query block at a time.
         # (S[0] already holds the next job's first scores and v[128:191] its K(1): rows and temporaries are score buffer 1,
         # whose P was consumed by the job's last P.V.)  A batch = the four 8-byte groups of one 32-column block; the stages
@@ -1073,10 +1141,11 @@ class Gen:
 
         def row_stores(qb):
             """[[instructions of one row store]] of query block qb (its rows are back in `rows`)"""
-            out = [[I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2),
-                    I("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, S_T[0], offen=1)]]
+            pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, S_T[0])
+            out = [[I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2)] + pre + [st]]
             for k in range(1, 8):
-                out.append([I("s_add_u32", S_T[0], S_T[0], S_T[1]), I("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0], offen=1)])
+                pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0])
+                out.append([I("s_add_u32", S_T[0], S_T[0], S_T[1])] + pre + [st])
             return out
 
         def read_back():
@@ -1133,11 +1202,13 @@ class Gen:
         e([x for grp in row_stores(1) for x in grp])
         e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the descriptor arithmetic below: it uses the stamp registers)
         # L store (lanes 0..31), in the I/O dtype: behind the row stores (they hold the vector-memory path for a while)
-        e(self.make_desc(S_SQ, S_L, S_LSB, S_LSH, S_B, S_HH))
+        e(self.make_desc(S_SQ, S_L, S_LSB, S_LSH, S_B, S_HH, 2))
         e(I("s_lshr_b64", EXEC, EXEC, 32))
         for qb in range(2):
-            e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), I("buffer_store_short", m2[qb], V(V_L2), S_SQ, S_T[0], offen=1))
+            pre, st = self.buf_op("buffer_store_short", m2[qb], V(V_L2), S_SQ, S_T[0])
+            e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), pre, st)
         e(I("s_mov_b64", EXEC, -1))
+        self.atmp_regs = (V_T[8], V_T[9])
 
     # ------------------------------------------------------------------ the whole kernel
     def build(self):
@@ -1150,7 +1221,7 @@ class Gen:
         self.k_decode_next()
         self.k_promote()
         e(comment("first job: K / V descriptors, K(0..2), V(0..1) by LDS-DMA, Q rows"))
-        e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH))
+        e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH, S_KSN), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH, S_VSN))
         e(I("s_mov_b32", S_KDMA, S_KW), I("s_mov_b32", S_VDMA, S_VW))
         e(self.stamp(0))
         for j in range(self.dk - 1):
@@ -1173,7 +1244,8 @@ class Gen:
         e(label(l_loop))
         for t4 in range(4):
             # causal: the last steady body starts the job's first diagonal tile in its last phase B
-            e(self.step(t4, steady=True, masks=(0, (S_LOOP, 1)) if self.causal and t4 == 3 else None))
+            tailm = ("tail", 0, (S_LOOP, 1)) if self.ragged and not self.causal else None
+            e(self.step(t4, steady=True, masks=((0, (S_LOOP, 1)) if self.causal else tailm) if t4 == 3 else None))
         e(I("s_sub_u32", S_LOOP, S_LOOP, 1), I("s_cmp_lg_u32", S_LOOP, 0), I("s_cbranch_scc1", Label(l_loop)))
         e(label(l_seam))
         e(self.stamp(3), self.stamp_acc(2), self.stamp_flush(), self.stamp_job(0))
@@ -1181,13 +1253,15 @@ class Gen:
         self.k_advance()
         cm = self.causal
         if True:
-            kpre = self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_NB, S_NHH) + [I("s_mov_b32", S_KDMA, S_KW)] + \
-                self.make_desc(S_NVRS, S_V, S_VSB, S_VSH, S_NB, S_NHH)
+            kpre = self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_NB, S_NHH, S_KSN) + [I("s_mov_b32", S_KDMA, S_KW)] + \
+                self.make_desc(S_NVRS, S_V, S_VSB, S_VSH, S_NB, S_NHH, S_VSN)
             vpre = [I("s_mov_b32", S_VRS.sub(k), S_NVRS.sub(k)) for k in range(4)] + [I("s_mov_b32", S_VDMA, S_VW)]
             sk, sv = 4 - self.dk, 4 - self.dv      # seam step whose phase B streams the next job's first K / V tile
             qs_setup, qs_pieces = self.q_stage(S_NB, S_NHH, S_NQI)
             for st in range(4):
                 kw = dict(masks=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None, cur_masks=(st,) if cm else None)
+                if self.ragged and not cm:   # keys at or behind N in the job's last four tiles (a ragged N has at least eight)
+                    kw = dict(masks=("tail", st + 1) if st < 3 else None, cur_masks=("tail", st))
                 early, pre = [], []
                 if st == 0:
                     # the next job's Q rows start their way into the wave's LDS slice: sixteen pieces, never more than one
@@ -1211,7 +1285,7 @@ class Gen:
                     # the job's last tile: its running maxima are put aside for the epilogue before the next job's first
                     # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
                     save = [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
-                    if cm:   # (behind the diagonal tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
+                    if cm or self.ragged:   # (behind the tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
                         kw.update(nxt_init=True, extra=[(self.LAZY_TAU["mr"] - self.PERIOD + 1, save)])
                     else:
                         kw.update(nxt_init=True, a_pre=save)
@@ -1281,9 +1355,10 @@ def main(argv=None):
     args = ap.parse_args(argv)
     from .check import check
     gens = []
-    for dtype in ("bf16", "f16"):
-        for causal in (False, True):
-            g = Gen(dtype, causal, stamps=args.stamps)
+    for dtype, causal, ragged in [(dt, c, False) for dt in ("bf16", "f16") for c in (False, True)] + \
+            ([] if args.stamps else [(dt, c, True) for dt in ("bf16", "f16") for c in (False, True)]):
+        if True:
+            g = Gen(dtype, causal, stamps=args.stamps, ragged=ragged)
             g.build()
             errs = check(g.prog)
             if errs:

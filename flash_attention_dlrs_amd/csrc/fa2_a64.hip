@@ -1,10 +1,12 @@
 // fa2_a64.hip -- host side of the generated assembly kernels `fa2_fwd_a64_<dtype>_<c|n>` (variant "a64"):
-// f16 / bf16, d = 128, N a multiple of 256; 4 waves x 64 query rows, one wave per SIMD with the whole register file,
+// f16 / bf16, d = 128, N >= 256 (a multiple of 256: the plain kernels; else the "ragged" ones: range-checked descriptors,
+// masked key tail); 4 waves x 64 query rows, one wave per SIMD with the whole register file,
 // persistent grid.  The kernels are produced by asm/fa2_a64_gen.py (instruction stream, register map and kernel-argument
 // layout are documented there), assembled into a gfx950 code object and embedded in this library (fa2_a64_blob.S); they
 // are loaded once per device with hipModuleLoadData and launched with hipModuleLaunchKernel.
 // Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -37,7 +39,7 @@ constexpr int kMaxDev = 64;
 struct DevState {
     bool ready = false, failed = false;
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [bf16 / f16][non-causal / causal]
+    hipFunction_t fn[2][2][2] = {};  // [bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
     int cus = 0;
 };
 DevState g_dev[kMaxDev];
@@ -64,10 +66,13 @@ DevState *dev_state() {
     }
     static const char *names[2][2] = {{"fa2_fwd_a64_bf16_n", "fa2_fwd_a64_bf16_c"}, {"fa2_fwd_a64_f16_n", "fa2_fwd_a64_f16_c"}};
     for (int t = 0; t < 2; ++t)
-        for (int c = 0; c < 2; ++c) {
-            e = hipModuleGetFunction(&d.fn[t][c], d.mod, names[t][c]);
-            if (e != hipSuccess) d.fn[t][c] = nullptr;  // a kernel the generator did not emit: reported at launch
-        }
+        for (int c = 0; c < 2; ++c)
+            for (int r = 0; r < 2; ++r) {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "%s%s", names[t][c], r ? "r" : "");
+                e = hipModuleGetFunction(&d.fn[t][c][r], d.mod, nm);
+                if (e != hipSuccess) d.fn[t][c][r] = nullptr;  // a kernel the generator did not emit: reported at launch
+            }
     (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
     d.cus = fa2_device_cus();
     d.ready = true;
@@ -78,7 +83,7 @@ DevState *dev_state() {
 
 bool fa2_a64_supports(const Fa2Problem &p) {
     if (p.dtype != FA2_DTYPE_BF16 && p.dtype != FA2_DTYPE_F16) return false;
-    if (p.d != 128 || p.N < 256 || (p.N & 255)) return false;
+    if (p.d != 128 || p.N < 256) return false;   // N a multiple of 256: the plain kernels; any other N above 256: the ragged ones
     if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
     if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
     const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
@@ -89,20 +94,20 @@ bool fa2_a64_supports(const Fa2Problem &p) {
         if (ptrs[k] & 15) return false;
     if (((p.qs[0] | p.qs[1] | p.ks[0] | p.ks[1] | p.vs[0] | p.vs[1] | p.os[0] | p.os[1]) & 7) != 0) return false;
     if ((uintptr_t)p.L & 1) return false;
-    const int64_t nq = p.N / 256, jobs = (int64_t)p.B * p.H * nq;
+    const int64_t nq = (p.N + 255) / 256, jobs = (int64_t)p.B * p.H * nq;
     if (jobs >= (1 << 22) || p.H >= (1 << 22) || p.ls[1] < p.N) return false;
     return true;
 }
 
 int fa2_launch_a64(const Fa2Problem &p) {
     if (!fa2_a64_supports(p)) {
-        fa2_set_error("a64 kernel: needs f16/bf16, d = 128, N a multiple of 256, unit d-stride, 16-byte aligned rows, "
+        fa2_set_error("a64 kernel: needs f16/bf16, d = 128, N >= 256, unit d-stride, 16-byte aligned rows, "
                       "scale > 0, N * row stride < 2 GiB");
         return FA2_ERR_UNSUPPORTED;
     }
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
-    hipFunction_t fn = d->fn[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0];
+    hipFunction_t fn = d->fn[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {
         fa2_set_error("a64 kernel: this (dtype, causal) form is not in the code object");
         return FA2_ERR_UNSUPPORTED;
@@ -114,7 +119,7 @@ int fa2_launch_a64(const Fa2Problem &p) {
     a.vs_b = p.vs[0] * 2; a.vs_h = p.vs[1] * 2; a.os_b = p.os[0] * 2; a.os_h = p.os[1] * 2;
     a.ls_b = p.ls[0] * 2; a.ls_h = p.ls[1] * 2;
     a.qs_n = (int32_t)(p.qs[2] * 2); a.ks_n = (int32_t)(p.ks[2] * 2); a.vs_n = (int32_t)(p.vs[2] * 2); a.os_n = (int32_t)(p.os[2] * 2);
-    a.N = p.N; a.H = p.H; a.nq = p.N / 256;
+    a.N = p.N; a.H = p.H; a.nq = (p.N + 255) / 256;
     a.nunit = p.causal ? (a.nq + 1) / 2 : a.nq;
     a.nbh = p.B * p.H;
     a.total = a.nunit * a.nbh;

@@ -63,7 +63,7 @@ extern "C" {
 #define FA2_VARIANT_MFMA16K 19 /* f16/bf16 small grids: 8 waves on a 128-row tile, waves w and w+4 split the KEYS and merge through LDS */
 #define FA2_VARIANT_MFMA16K_R2K2 20 /* same with a 64-row tile: 2 row blocks x 2 key groups, four waves                    */
 #define FA2_VARIANT_MFMA16K_R2K4 23 /* 64-row tile, 2 row blocks x 4 key groups, eight waves (d = 64)                       */
-#define FA2_VARIANT_A64 24 /* f16/bf16, d = 128, N % 256 == 0: generated gfx950 assembly, 4 waves x 64 rows, one wave per SIMD   */
+#define FA2_VARIANT_A64 24 /* f16/bf16, d = 128, N >= 256 (any): generated gfx950 assembly, 4 waves x 64 rows, one wave per SIMD */
                            /* with the whole register file (O, Q, V^T in AGPRs), persistent grid, continuous tile stream.     */
                            /* Non-finite inputs: as the reference, except that a NaN in query row q also makes row q ^ 16 of   */
                            /* the same 32-row block NaN (the row sums run on the matrix pipe, where q ^ 16's P meets a zero    */

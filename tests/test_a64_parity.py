@@ -73,7 +73,8 @@ def test_scale_and_default_table(oracle, dtype, scale):
 def test_default_table_picks_a64_for_the_north_star_shape():
     assert _lib.query_tile(4096, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64
     assert _lib.query_tile(8192, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
-    assert _lib.query_tile(4000, 128, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64   # N not a multiple of 256
+    assert _lib.query_tile(4000, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64   # N not a multiple of 256: the ragged kernels
+    assert _lib.query_tile(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64    # d = 64
 
 
 def test_many_jobs_per_workgroup_and_job_order(oracle):
@@ -232,8 +233,32 @@ def test_nan_and_inf_inputs_propagate_like_the_oracle(oracle, variant):
     assert (O.float()[~bad] - O_ref[~bad]).abs().max() <= O_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_ragged_N_vs_oracle(oracle, dtype, causal):
+    """N above 256 that is not a multiple of 256: the "ragged" kernels (range-checked descriptors with every offset in the VGPR
+    operand: rows past N load as zeros and are never stored; non-causal: the key tail of the job's last four tiles is masked --
+    a partly real tile exactly, wholly unreal ones through +inf as running maximum).  Element-wise against the oracle's
+    deferred-maximum mode; O and L sit in canary arenas."""
+    for N in (257, 300, 448, 600, 1000, 1333, 2049):
+        B, H = 2, 3
+        Q, K, V = rand3((B, H, N, 128), dtype, seed=N)
+        arena_o = torch.full((B, H, N + 8, 128), 768.0, dtype=dtype, device=DEV)
+        arena_l = torch.full((B, H, N + 8, 1), 768.0, dtype=dtype, device=DEV)
+        O, L = arena_o[:, :, :N], arena_l[:, :, :N]
+        _lib.fa2_fwd(Q.to(DEV), K.to(DEV), V.to(DEV), O, L, fa.convert_triton_dtype(dtype), causal=causal, variant=_lib.VARIANT_A64)
+        torch.cuda.synchronize()
+        assert (arena_o[:, :, N:].float() == 768.0).all() and (arena_l[:, :, N:].float() == 768.0).all(), N
+        f = lambda t: t.float().numpy()
+        O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
+                                               thr=60.0 if dtype == torch.bfloat16 else 12.0, sum_rounded=True)
+        O_ref, L_ref = torch.from_numpy(O_ref), torch.from_numpy(L_ref)
+        assert (O.cpu().float() == O_ref).float().mean() >= 0.99, N
+        check(O.cpu(), L.cpu(), O_ref, L_ref, dtype)
+
+
 def test_unsupported_shapes_raise_and_auto_falls_back():
-    Q, K, V = rand3((1, 2, 300, 128), torch.bfloat16, seed=1)
+    Q, K, V = rand3((1, 2, 200, 128), torch.bfloat16, seed=1)
     with pytest.raises(TypeError):
         a64(Q, K, V)
     O, _ = a64(Q, K, V, variant="auto")

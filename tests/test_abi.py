@@ -119,7 +119,8 @@ def test_static_tile_table():
     # north-star config c3 and friends take the MFMA paths; odd head sizes and exotic dtypes fall back
     assert q(4096, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64          # north-star shape (c3): the assembly kernel
     assert q(4096, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
-    assert q(4096 + 64, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_MFMA16H  # N not a multiple of 256
+    assert q(4096 + 64, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64      # (N not a multiple of 256: its ragged form)
+    assert q(200, 128, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64            # below one 256-row job
     assert q(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_MFMA16H
     assert q(1024, 64, _lib.FA2_DTYPE_F16)[0] in (_lib.VARIANT_MFMA16H, _lib.VARIANT_MFMA16D_W4)
     assert q(256, 128, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32

@@ -103,6 +103,23 @@ def test_emulated_causal_diagonal_with_large_masked_scores(oracle, dtype, thr):
     assert np.abs(L - L_ref.reshape(L.shape)).max() <= 1.01 * ulp
 
 
+@pytest.mark.parametrize("dtype,causal,N", [("bf16", False, 300), ("bf16", False, 600), ("f16", False, 1000), ("bf16", True, 448), ("f16", True, 520)])
+def test_emulated_ragged_kernels(oracle, dtype, causal, N):
+    """N not a multiple of 256: the buffers hold exactly N rows (an unchecked access faults in the emulator), two (b, h) on one
+    workgroup.  300: the job's last 256 keys hold 44 real ones (tile 0 partial, tiles 1-3 unreal); 600: 88 (tile 1 partial);
+    1000: 232 (tile 3 partial)"""
+    rng = np.random.default_rng(N)
+    Q, K, V = (rng.standard_normal((1, 2, N, 128)).astype(np.float32) for _ in range(3))
+    g = Gen(dtype, causal, ragged=True)
+    O, L, _ = harness.run(g.build(), Q, K, V, dtype=dtype, causal=causal, nwg=1)
+    rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
+    O_ref, L_ref = oracle.forward_deferred(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=causal, G=32, B_c=64,
+                                           thr=60.0 if dtype == "bf16" else 12.0)
+    assert not np.isnan(O).any() and np.abs(O - O_ref).max() <= O_TOL[dtype]
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(L_ref).max())) - (7 if dtype == "bf16" else 10))
+    assert np.abs(L - L_ref[..., 0]).max() <= 1.01 * ulp
+
+
 def test_emulated_kernel_rescale_path(oracle):
     _run(oracle, "bf16", False, 1, 1, 512, spike=True, seed=2)
 
