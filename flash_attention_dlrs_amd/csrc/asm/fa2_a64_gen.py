@@ -122,6 +122,7 @@ VBASE = 32768
 VB = (0, 16384)                  # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
 EPI = 65536                      # + 16384 * wave: the wave's private 64 x 256-byte slice: the next job's Q rows land here by
                                  # LDS-DMA (K-tile image) on their way to a[128:191]; later the job's O rows leave through it
+ZERO_K = 131072           # causal: 32 KiB of zeros behind the buffers, the K "tile" of waves for which a diagonal tile is hidden
 LDS_TOTAL = 131072
 
 KARG_SIZE = 192
@@ -375,6 +376,15 @@ class Gen:
             e(comment("ragged, non-causal: real keys in a job's last 256; -inf"),
               I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
               I("v_mov_b32", NINF, float("-inf")))
+        if self.causal:
+            # the zero K "tile": a wave for which a whole diagonal tile is hidden reads its K fragments from here, so that the
+            # 32 MFMAs of that tile multiply zeros (the matrix pipe's power follows its operands: all-zero inputs run the same
+            # instruction stream 37 % faster at the package power limit) -- P of such a tile is zero anyway
+            e(comment("causal: 32 KiB of zeros in LDS"),
+              [I("v_mov_b32", V(V_T[4 + k]), 0) for k in range(4)],
+              I("v_lshlrev_b32", t0, 4, lane), I("s_lshl_b32", S_T[0], S_WAVE, 13), I("v_add_u32", t0, S_T[0], t0),
+              I("v_add_u32", t0, ZERO_K, t0),
+              [I("ds_write_b128", t0, V(V_T[4], 4), offset=1024 * k) for k in range(8)])
         if self.causal:
             e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
@@ -976,7 +986,7 @@ class Gen:
         return out
 
     def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
-                pre=(), early=(), late=(), masks=None, own_gaps=None):
+                pre=(), early=(), late=(), masks=None, own_gaps=None, post=()):
         """B(t), t4 = t & 3: P.V(t) and the row sums of P(t) from S[p]  ||  the middle softmax operations of tile t+1 (on S[1-p])
         ||  K(t+2) reads from KB[(t+2) % R]  ||  LDS-DMA V(t+dv) -> VB[(t+dv) % R], K(t+dk) -> KB[(t+dk) % R].
         pre: instructions ahead of the phase;  early: scalar work / register loads spread over the first gaps;
@@ -989,7 +999,7 @@ class Gen:
         gaps = {}
         add = lambda k, order, ins: gaps.setdefault(min(max(int(k), 0), NB - 1), []).append((order, ins))
         head = list(pre)
-        post = []
+        post, post_arg = [], list(post)
         if with_kread and "nokread" not in abl:
             for k, ins in enumerate(self.k_reads((t4 + 2) % self.R)):
                 add(self.b_kread_gap(k), 0, [ins])
@@ -1031,7 +1041,7 @@ class Gen:
             body = [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
         else:
             body = self.emit_phase(mf, gaps)
-        body = head + body + post
+        body = head + body + post + post_arg
         if nxt and not nxt_init or True:
             # deferred rescale of O and the row sums by the factors the decisions of this step left (rare)
             l_rs, l_back = self.lab("rescale"), self.lab("rescale_back")
@@ -1068,7 +1078,7 @@ class Gen:
         """one tile step, t4 = t & 3"""
         ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady", "dma", "cur_masks", "extra")}
         kb = {k: v for k, v in kw.items() if k in ("with_pv", "nxt", "nxt_init", "with_kread", "with_dma", "steady", "pre", "early", "late",
-                                                   "own_gaps")}
+                                                   "own_gaps", "post")}
         if kw.get("masks") is not None:   # the masking tests of a score group sit in front of its first row-maximum operation
             ka["masks"] = kw["masks"]
             kb["masks"] = kw["masks"]
@@ -1275,6 +1285,12 @@ class Gen:
                     kw.update(vm=self.vm + 12,
                               dma=[(g, *qs_pieces[8 + k]) for k, g in enumerate((24, 26, 28, 30))],
                               late=[(g, *qs_pieces[12 + k]) for k, g in enumerate((1, 3, 5, 7))])
+                if cm and st in (0, 1):
+                    # this step's phase B reads the K fragments of diagonal tile st + 2: zeros for the waves below that diagonal
+                    jd = st + 2
+                    pre += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cselect_b32", S_X2, ZERO_K, 0),
+                            I("v_add_u32", V(V_KRE), S_X2, V(V_KRE)), I("v_add_u32", V(V_KRO), S_X2, V(V_KRO))]
+                    kw.update(post=[I("v_subrev_u32", V(V_KRE), S_X2, V(V_KRE)), I("v_subrev_u32", V(V_KRO), S_X2, V(V_KRO))])
                 if st == sk:
                     early += kpre
                 if st == sv:
@@ -1308,12 +1324,15 @@ class Gen:
         return self.prog
 
     # ------------------------------------------------------------------ text
+    def lds_total(self):
+        return LDS_TOTAL + (32768 if getattr(self, "causal", False) else 0)
+
     def text(self):
         lines = [f".protected {self.name}", f".globl {self.name}", ".p2align 8", f".type {self.name},@function", f"{self.name}:"]
         lines += [x.text() for x in self.prog]
         lines += [f".L{self.name}_fend:", f".size {self.name}, .L{self.name}_fend-{self.name}", "",
                   '.section .rodata,"a",@progbits', ".p2align 6, 0x0", f".amdhsa_kernel {self.name}",
-                  f"  .amdhsa_group_segment_fixed_size {LDS_TOTAL}", "  .amdhsa_private_segment_fixed_size 0",
+                  f"  .amdhsa_group_segment_fixed_size {self.lds_total()}", "  .amdhsa_private_segment_fixed_size 0",
                   f"  .amdhsa_kernarg_size {KARG_SIZE}", "  .amdhsa_user_sgpr_count 2", "  .amdhsa_user_sgpr_kernarg_segment_ptr 1",
                   "  .amdhsa_system_sgpr_workgroup_id_x 1", "  .amdhsa_system_vgpr_workitem_id 0",
                   "  .amdhsa_next_free_vgpr 512", "  .amdhsa_next_free_sgpr 102", "  .amdhsa_accum_offset 256",
@@ -1325,7 +1344,7 @@ class Gen:
     def metadata(self):
         return "\n".join([
             f"  - .args:", f"      - .offset: 0", f"        .size: {KARG_SIZE}", f"        .value_kind: by_value",
-            f"    .group_segment_fixed_size: {LDS_TOTAL}", f"    .kernarg_segment_align: 8", f"    .kernarg_segment_size: {KARG_SIZE}",
+            f"    .group_segment_fixed_size: {self.lds_total()}", f"    .kernarg_segment_align: 8", f"    .kernarg_segment_size: {KARG_SIZE}",
             f"    .max_flat_workgroup_size: 256", f"    .name: {self.name}", f"    .private_segment_fixed_size: 0",
             f"    .sgpr_count: 108", f"    .symbol: {self.name}.kd", f"    .vgpr_count: 512", f"    .agpr_count: 256",
             f"    .wavefront_size: 64"])
