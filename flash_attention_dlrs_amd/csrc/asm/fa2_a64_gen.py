@@ -554,12 +554,17 @@ class Gen:
     def qk_mfmas(self, Y, cinit=None):
         """S^T(next) chains g = 2 qb + kb into score buffer Y.  cinit[g]: None -> C = 0, Reg -> C operand of the first MFMA"""
         out = []
-        for g in range(4):
+        if "qk_chain_order" in self.abl:     # (the round's first order: one chain after the other)
+            order = [(g, ks) for g in range(4) for ks in range(8)]
+        else:
+            # the two chains of a query block interleaved: consecutive MFMAs share their B operand (the Q fragment) -- half the
+            # operand toggling of the matrix pipe's inputs, and no MFMA follows the one it accumulates onto
+            order = [(2 * qb + kb, ks) for qb in range(2) for ks in range(8) for kb in range(2)]
+        for g, ks in order:
             qb, kb = g >> 1, g & 1
             d = V(Y + 16 * g, 16)
-            for ks in range(8):
-                c = d if ks else (cinit[g] if cinit and cinit[g] is not None else 0)
-                out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}"))
+            c = d if ks else (cinit[g] if cinit and cinit[g] is not None else 0)
+            out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}"))
         return out
 
     def pv_mfmas(self, X):
@@ -602,7 +607,7 @@ class Gen:
     NB = 40
     PERIOD = 72
     T_END = 104
-    LAZY_TAU = {"ms0": 27, "ms1": 28, "mr": 98, "pm": 99}   # tau of the lazy-masking operations of a diagonal tile (mask_lazy)
+    LAZY_TAU = {"ms0": 28, "ms1": 29, "mr": 99, "pm": 100}   # tau of the lazy-masking operations of a diagonal tile (mask_lazy)
 
     def tile_plan(self, init=False, lean=False):
         """placement of the per-tile softmax operations: returns [(tau, kind, payload)] sorted by tau.
@@ -643,7 +648,8 @@ class Gen:
         # row maxima: chain g may start 3 gaps after its last QK^T MFMA (12 wait states), one operation per gap and chain
         t_mx = {}
         for g in range(4):
-            t = 8 * g + 11
+            # (chain g's last MFMA is number 8 g + 7, or 16 qb + 14 + kb with the chains of a query block interleaved)
+            t = 8 * g + 11 if "qk_chain_order" in self.abl else 16 * (g >> 1) + 18 + (g & 1)
             for j in range(8):
                 t = place(t, 5, "mx", (g, j)) + 1
             t_mx[g] = t
