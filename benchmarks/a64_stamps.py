@@ -77,6 +77,9 @@ out["wg_len"] = q(en - st)
 out["wg_end_rel"] = q(en - st.min())
 out["wg_len_by_xcd_us"] = [round(float((en - st)[x::8].mean()) / 1e3, 1) for x in range(8)]   # workgroup id % 8 = XCD
 out["wg_len_spread_in_xcd_us"] = [round(float(((en - st)[x::8].max() - (en - st)[x::8].min())) / 1e3, 1) for x in range(8)]
+# pipeline fill of the workgroup's first job: kernel start -> first tiles landed (set-up, descriptors, DMA issue, HBM latency) ->
+# end of step -1 (Q / K fragment reads, first QK^T, start of the first softmax)
+out["fill_cyc"] = [float((d[..., 1] - d[..., 8]).median()), float((d[..., 2] - d[..., 1]).median())]
 real = (d[..., 7] - d[..., 6]).median().item()  # 100 MHz ticks
 out["clock_ghz"] = round(float(seg["kernel"].median()) / real / 10.0, 3) if real > 0 else None
 out["job_cyc"] = float((d[..., 5] - d[..., 0]).median())

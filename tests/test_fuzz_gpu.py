@@ -49,6 +49,8 @@ def test_random_shape(B, H, N, d, dtype, causal):
     fwd_variants = ["auto", "generic"]
     if dtype != torch.float32 and d in (64, 128):
         fwd_variants += ["mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16k", "mfma16k_r2k2"] + ([] if d == 128 else ["mfma16k_r2k4"])
+    if dtype != torch.float32 and d == 128 and N >= 256:
+        fwd_variants += ["a64"]      # (its plain form when N is a multiple of 256, the ragged one otherwise)
     if dtype == torch.float32 and d in (64, 128):
         fwd_variants += ["mfma32"]
     for v in fwd_variants:
@@ -64,3 +66,35 @@ def test_random_shape(B, H, N, d, dtype, causal):
             bound = (2e-4 if dtype == torch.float32 else REL[dtype]) * max(1.0, t.abs().max().item())
             assert err <= bound, ("bwd", v, name, err, bound)
     assert math.isfinite(L.float().abs().max().item())
+
+
+def a64_cases():
+    rng = random.Random(4242)
+    out = []
+    for k in range(24):
+        N = rng.choice([256, 257, 300, 511, 512, 513, 700, 767, 768, 769, 1000, 1024, 1025, 1279, 1500, 2047, 2048, 2049, 2500]) if k % 2 else rng.randint(256, 3000)
+        B, H = rng.choice([(1, 1), (1, 3), (2, 4), (1, 8), (3, 8), (2, 5), (4, 16), (1, 40)])
+        out.append((B, H, N, rng.choice([torch.bfloat16, torch.float16]), bool(k & 1), rng.choice([1.0, 1.0, 128 ** -0.5, 0.3]),
+                    rng.choice(["contiguous", "bnhd", "padded_rows"])))
+    return out
+
+
+@pytest.mark.parametrize("B,H,N,dtype,causal,scale,layout", a64_cases(), ids=lambda v: str(v).replace("torch.", ""))
+def test_random_a64_problem(B, H, N, dtype, causal, scale, layout):
+    """the generated assembly kernel over random (B, H, N) -- one job to many per workgroup, N ragged or not -- scales and
+    storage layouts ((B, N, H, d) permuted views, rows padded to 136 elements), against fp64 attention on the device"""
+    g = torch.Generator().manual_seed(N * 7919 + B * 31 + H)
+    mk = {"contiguous": lambda: (torch.randn(B, H, N, 128, generator=g) * 0.7).to(dtype).to(DEV),
+          "bnhd": lambda: (torch.randn(B, N, H, 128, generator=g) * 0.7).to(dtype).to(DEV).transpose(1, 2),
+          "padded_rows": lambda: (torch.randn(B, H, N, 136, generator=g) * 0.7).to(dtype).to(DEV)[..., :128]}[layout]
+    Q, K, V = mk(), mk(), mk()
+    O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal, scale=scale, variant="a64")
+    q, k, v = (t.double() for t in (Q, K, V))
+    S = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        S = S.masked_fill(~torch.ones(N, N, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+    O_t = torch.softmax(S, dim=-1) @ v
+    L_t = torch.logsumexp(S, dim=-1, keepdim=True) * math.log2(math.e)
+    assert (O.double() - O_t).abs().max().item() <= REL[dtype] * max(1.0, O_t.abs().max().item())
+    lu = 2.0 ** (math.floor(math.log2(max(L_t.abs().max().item(), 1e-9))) - (7 if dtype == torch.bfloat16 else 10))
+    assert (L.double() - L_t).abs().max().item() <= 1.01 * lu
