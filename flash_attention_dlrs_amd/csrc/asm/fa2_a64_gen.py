@@ -122,7 +122,6 @@ VBASE = 32768
 VB = (0, 16384)                  # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
 EPI = 65536                      # + 16384 * wave: the wave's private 64 x 256-byte slice: the next job's Q rows land here by
                                  # LDS-DMA (K-tile image) on their way to a[128:191]; later the job's O rows leave through it
-ZERO_K = 131072           # causal: 32 KiB of zeros behind the buffers, the K "tile" of waves for which a diagonal tile is hidden
 LDS_TOTAL = 131072
 
 KARG_SIZE = 192
@@ -130,7 +129,8 @@ NSLOT = 24
 
 
 class Gen:
-    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False):
+    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
+                 caps=(5, 24)):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
@@ -143,6 +143,7 @@ class Gen:
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
+        self.caps = caps       # fillers / issue cycles a gap behind a 32x32x16 MFMA may carry in the softmax plan
         self.ragged = ragged   # N is not a multiple of 256: range-checked descriptors, every offset in the VGPR operand, masked key tail
         assert not (ragged and stamps), "the ragged kernels use the stamps' temporaries as address registers"
         self.vread_double = vread_double   # phase-A gaps that carry two V transposed reads (the last read sits in gap 31 - this)
@@ -377,15 +378,6 @@ class Gen:
               I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
               I("v_mov_b32", NINF, float("-inf")))
         if self.causal:
-            # the zero K "tile": a wave for which a whole diagonal tile is hidden reads its K fragments from here, so that the
-            # 32 MFMAs of that tile multiply zeros (the matrix pipe's power follows its operands: all-zero inputs run the same
-            # instruction stream 37 % faster at the package power limit) -- P of such a tile is zero anyway
-            e(comment("causal: 32 KiB of zeros in LDS"),
-              [I("v_mov_b32", V(V_T[4 + k]), 0) for k in range(4)],
-              I("v_lshlrev_b32", t0, 4, lane), I("s_lshl_b32", S_T[0], S_WAVE, 13), I("v_add_u32", t0, S_T[0], t0),
-              I("v_add_u32", t0, ZERO_K, t0),
-              [I("ds_write_b128", t0, V(V_T[4], 4), offset=1024 * k) for k in range(8)])
-        if self.causal:
             e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
               I("v_sub_u32", V(V_IMH), t0, t3),   # i - 4 h
@@ -619,8 +611,8 @@ class Gen:
         slots = [0.0] * P
         cost = [0.0] * P
         nexp = [0] * P
-        cap_s = [5.0] * P
-        cap_c = [24.0] * P
+        cap_s = [float(self.caps[0])] * P
+        cap_c = [float(self.caps[1])] * P
         # phase B: the gap behind a 16x16x32 row-sum MFMA is half as long
         for b in self.b_short_gaps():
             cap_s[32 + b], cap_c[32 + b] = 2.0, 8.0
@@ -714,6 +706,11 @@ class Gen:
         return r
 
     def b_kread_gap(self, k):
+        if "kfront" in self.abl:     # (experiment) two K reads per gap from the start of the phase
+            g = k // 2
+            while g in self.b_short_gaps():
+                g += 1
+            return g
         g = 2 * k
         while g in self.b_short_gaps():
             g += 1
@@ -1291,12 +1288,6 @@ class Gen:
                     kw.update(vm=self.vm + 12,
                               dma=[(g, *qs_pieces[8 + k]) for k, g in enumerate((24, 26, 28, 30))],
                               late=[(g, *qs_pieces[12 + k]) for k, g in enumerate((1, 3, 5, 7))])
-                if cm and st in (0, 1):
-                    # this step's phase B reads the K fragments of diagonal tile st + 2: zeros for the waves below that diagonal
-                    jd = st + 2
-                    pre += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cselect_b32", S_X2, ZERO_K, 0),
-                            I("v_add_u32", V(V_KRE), S_X2, V(V_KRE)), I("v_add_u32", V(V_KRO), S_X2, V(V_KRO))]
-                    kw.update(post=[I("v_subrev_u32", V(V_KRE), S_X2, V(V_KRE)), I("v_subrev_u32", V(V_KRO), S_X2, V(V_KRO))])
                 if st == sk:
                     early += kpre
                 if st == sv:
@@ -1308,11 +1299,44 @@ class Gen:
                     # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
                     save = [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
                     if cm or self.ragged:   # (behind the tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
-                        kw.update(nxt_init=True, extra=[(self.LAZY_TAU["mr"] - self.PERIOD + 1, save)])
+                        kw.update(nxt_init=True, extra=list(kw.get("extra", ())) + [(self.LAZY_TAU["mr"] - self.PERIOD + 1, save)])
                     else:
                         kw.update(nxt_init=True, a_pre=save)
                 e(self.stamp(16 + st))
+                lean = cm and st >= 1 and "nolean" not in self.abl
+                half = cm and st < 3 and "nolean" not in self.abl
+                if lean:
+                    # waves below this step's diagonal tile (w < st): the tile whose softmax finishes and whose P.V runs here is
+                    # hidden from them, and so is the one that starts (steps 1, 2; step 3 starts the next job's first tile).
+                    # They take a body with the same loads, DMA pieces, waits and barriers but without those MFMAs and softmax
+                    # operations, and idle at the barriers: at the package power limit what one wave does not execute, the
+                    # others run faster (+1.2 % on c3 causal, A/B in one process).  Such a wave's running maximum was swapped for
+                    # +inf when the hidden tile started ('ms'): the lean body puts it back.
+                    l_lean, l_join = self.lab("lean"), self.lab("lean_join")
+                    e(I("s_cmp_lt_u32", S_WAVE, st), I("s_cbranch_scc1", Label(l_lean)))
+                if half:
+                    # the wave ON this step's diagonal (w == st): the tile that starts here is hidden from it -- no QK^T, no start
+                    # of its softmax (+0.2 % at c3, +1 % at N = 2048 on top of the lean bodies)
+                    l_half = self.lab("half")
+                    l_join2 = l_join if lean else self.lab("half_join")
+                    e(I("s_cmp_eq_u32", S_WAVE, st), I("s_cbranch_scc1", Label(l_half)))
                 e(self.step(st, early=early, pre=pre, **kw))
+                if lean or half:
+                    e(label(l_join if lean else l_join2))
+                    body, self.prog = self.prog, []
+                    if lean:
+                        lkw = dict(kw)
+                        lkw["a_pre"] = [I("v_mov_b32", V(V_MC[qb]), V(V_MSV[qb])) for qb in range(2)] + list(kw.get("a_pre", ()))
+                        lkw.update(dict(with_qk=False, cur=False, nxt=False, with_pv=False) if st < 3 else dict(cur=False, with_pv=False))
+                        e(label(l_lean), self.step(st, early=early, pre=pre, **lkw), I("s_branch", Label(l_join)))
+                    if half:
+                        hkw = dict(kw)
+                        # (no 'ms' runs for the hidden tile: the lean body of the next step restores from V_MSV all the same)
+                        hkw["a_pre"] = list(kw.get("a_pre", ())) + [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
+                        hkw.update(with_qk=False, nxt=False)
+                        e(label(l_half), self.step(st, early=early, pre=pre, **hkw), I("s_branch", Label(l_join2)))
+                    self.ool.append(self.prog)
+                    self.prog = body
         e(self.stamp(4), self.stamp_job(1))
         self.k_epilogue()
         e(self.stamp(5))
@@ -1331,7 +1355,7 @@ class Gen:
 
     # ------------------------------------------------------------------ text
     def lds_total(self):
-        return LDS_TOTAL + (32768 if getattr(self, "causal", False) else 0)
+        return LDS_TOTAL
 
     def text(self):
         lines = [f".protected {self.name}", f".globl {self.name}", ".p2align 8", f".type {self.name},@function", f"{self.name}:"]
@@ -1365,6 +1389,14 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
              "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire")}
 
 
+# named variants of the experiments build (make experiments; FA2_A64_KERNEL=fa2_fwd_a64_bf16_<c|n>_<tag> selects one per launch:
+# benchmarks/variants.py interleaves them in one process, which resolves +-0.3 % -- across gpurun calls boxes differ by 7 %).
+# Measured that way on c3 causal: nolean -1.0 %; plan capacities (6, 26) / (6, 24) / (5, 26) / (5, 25) +-0.3 %, (7, 28) -1.7 %;
+# one-chain-after-the-other QK^T order -0.2 %; zero-operand K and V^T fragments for hidden tiles +0.4 % / 0 (dropped for the
+# lean bodies); V reads doubled up in 2 instead of 4 gaps 0.
+VARIANTS = {"base": dict(), "nolean": dict(abl=("nolean",)), "chain": dict(abl=("qk_chain_order",)), "caps626": dict(caps=(6, 26))}
+
+
 def module_text(gens):
     head = ['.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', ".amdhsa_code_object_version 6", ".text", ""]
     body = "\n".join(head) + "\n".join(g.text() for g in gens)
@@ -1377,6 +1409,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("-o", "--output", required=True)
     ap.add_argument("--stamps", action="store_true", help="diagnostic build: job-timeline stamps into the debug buffer")
+    ap.add_argument("--variants", action="store_true", help="experiments build: the product kernels plus named variants (A/B in one process)")
     args = ap.parse_args(argv)
     from .check import check
     gens = []
@@ -1398,6 +1431,12 @@ def main(argv=None):
             g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
             g.build()
             gens.append(g)
+    if args.variants:   # selected at run time through FA2_A64_KERNEL in the experiments library (benchmarks/variants.py)
+        for tag, kw in VARIANTS.items():
+            for causal in (False, True):
+                g = Gen("bf16", causal, name=f"fa2_fwd_a64_bf16_{'c' if causal else 'n'}_{tag}", **kw)
+                g.build()
+                gens.append(g)
     with open(args.output, "w") as f:
         f.write(module_text(gens))
     return 0

@@ -149,6 +149,17 @@ int fa2_launch_a64(const Fa2Problem &p) {
                    ? (uint32_t)(lg2(p.H) | (lg2(a.group) << 8) | (lg2(gn) << 16) | (1 << 24)) : 0u;
         a.pad = 0;
     }
+#ifdef FA2_A64_VARIANTS
+    // experiments library only (make experiments): a named variant of the kernel from the same code object, for A/B runs in
+    // one process (benchmarks/variants.py: "c3:a64:FA2_A64_KERNEL=fa2_fwd_a64_bf16_c_lean")
+    {
+        const char *kn = getenv("FA2_A64_KERNEL");
+        if (kn && *kn && hipModuleGetFunction(&fn, d->mod, kn) != hipSuccess) {
+            fa2_set_error("a64 experiments build: kernel %s not found", kn);
+            return FA2_ERR_BAD_ARG;
+        }
+    }
+#endif
 #ifdef FA2_A64_STAMPS
     // diagnostic library only (make stamps): the kernels carry s_memtime stamps and write them to the buffer whose device
     // address the harness passes in FA2_A64_DBG (benchmarks/a64_stamps.py)
