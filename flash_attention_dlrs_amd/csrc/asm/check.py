@@ -7,7 +7,7 @@ every instruction in between counts one, `s_nop N` counts N + 1):
   R3  transcendental result -> other VALU: >= 1
   R4  VALU result -> v_permlane32_swap operand: >= 2
   R5  VALU result -> v_readfirstlane source: >= 1
-  R6  VALU-written SGPR (v_readfirstlane, v_cmp) -> VMEM / SMEM / SALU reader: >= 5 (only VMEM needs it; kept strict)
+  R6  VALU-written SGPR (v_readfirstlane, v_cmp) -> memory instruction reading it: >= 5 (SALU readers are interlocked)
   R7  SALU write of M0 -> LDS-DMA: >= 1
   R8  MFMA C operand -> overwritten by VALU: >= 12
   R9  (not a wait state: a scheduling invariant) the SCC an instruction consumes was produced by the instruction meant to
@@ -207,7 +207,10 @@ def check(prog, verbose=True):
                     for r in u:
                         if r in last_valu_def and dist(last_valu_def[r]) < 1:
                             errs.append((idx, "R5 valu->readfirstlane", r, dist(last_valu_def[r])))
-            elif not ins.op.startswith("s_cbranch_vcc"):  # v_cmp -> s_cbranch_vcc* needs nothing (hipcc emits them adjacent)
+            elif ins.op.startswith("buffer_") or ins.op.startswith("global_") or ins.op.startswith("ds_") or ins.op.startswith("s_load"):
+                # memory instructions reading an SGPR a VALU wrote (the ISA's manual wait states list VMEM; a scalar ALU
+                # instruction or branch reading it is interlocked by the hardware -- hipcc emits v_cmp / s_cbranch_vccnz and
+                # v_readfirstlane / s_add back to back)
                 for r in u:
                     if r[0] == "s" and r in last_valu_sgpr and dist(last_valu_sgpr[r]) < 5:
                         errs.append((idx, "R6 valu sgpr->reader", r, dist(last_valu_sgpr[r])))
