@@ -14,6 +14,16 @@ import shutil
 import sys
 
 
+def newest_run(files):
+    """gpurun merges new output into the local gpurun_out/: keep only the files of the most recent profiler process per directory
+    (rocprofv3 prefixes its files with its process id)"""
+    files = list(files)
+    if not files:
+        return files
+    pid = os.path.basename(max(files, key=os.path.getmtime)).split("_")[0]
+    return [f for f in files if os.path.basename(f).split("_")[0] == pid]
+
+
 def main():
     src, dst, tag, kfilter, workload = sys.argv[1:6]
     os.makedirs(dst, exist_ok=True)
@@ -22,11 +32,11 @@ def main():
         if not os.path.isdir(d):
             continue
         vals, durs = {}, []
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest_run(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
             for r in csv.DictReader(open(f)):
                 if kfilter in r["Kernel_Name"]:
                     vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for f in newest_run(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
             for r in csv.DictReader(open(f)):
                 if kfilter in r["Kernel_Name"]:
                     durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -35,7 +45,7 @@ def main():
         if durs:
             kern_ns[os.path.basename(d)] = sum(durs) / len(durs)
     stats = None
-    for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest_run(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
         for r in csv.DictReader(open(f)):
             if kfilter in r["Name"]:
