@@ -257,6 +257,24 @@ def test_ragged_N_vs_oracle(oracle, dtype, causal):
         check(O.cpu(), L.cpu(), O_ref, L_ref, dtype)
 
 
+def test_two_streams_at_once():
+    """the launcher keeps no per-launch state: two a64 problems in flight on two streams give the bits of the serial runs"""
+    torch.manual_seed(3)
+    a = [torch.randn(2, 16, 2048, 128, device=DEV).bfloat16() for _ in range(3)]     # causal, 256 jobs
+    b = [torch.randn(1, 24, 1000, 128, device=DEV).half() for _ in range(3)]         # ragged, non-causal
+    Oa, La = fa.flash_attention_forward(*a, DEV, causal=True, variant="a64")
+    Ob, Lb = fa.flash_attention_forward(*b, DEV, causal=False, variant="a64")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            Oa2, La2 = fa.flash_attention_forward(*a, DEV, causal=True, variant="a64")
+        with torch.cuda.stream(s2):
+            Ob2, Lb2 = fa.flash_attention_forward(*b, DEV, causal=False, variant="a64")
+    torch.cuda.synchronize()
+    assert torch.equal(Oa, Oa2) and torch.equal(La, La2) and torch.equal(Ob, Ob2) and torch.equal(Lb, Lb2)
+
+
 def test_unsupported_shapes_raise_and_auto_falls_back():
     Q, K, V = rand3((1, 2, 200, 128), torch.bfloat16, seed=1)
     with pytest.raises(TypeError):
