@@ -21,6 +21,11 @@ class MB:
         e(I("s_load_dwordx4", S(4, 4), S(0, 2), 0))
         e(I("v_and_b32", V(200), 63, V(0)))
         e(I("v_lshlrev_b32", V(201), 4, V(200)))            # lane * 16: an LDS / buffer offset
+        # store patterns: V(206) = (lane >> 4) * 256 + (lane & 15) * 16  (4 whole rows);  V(207) = (lane & 31) * 256 + (lane >> 5) * 8
+        e(I("v_lshrrev_b32", V(206), 4, V(200))), e(I("v_lshlrev_b32", V(206), 8, V(206))), e(I("v_and_b32", V(207), 15, V(200)))
+        e(I("v_lshl_add_u32", V(206), V(207), 4, V(206)))
+        e(I("v_and_b32", V(207), 31, V(200))), e(I("v_lshlrev_b32", V(207), 8, V(207))), e(I("v_lshrrev_b32", V(205), 5, V(200)))
+        e(I("v_lshl_add_u32", V(207), V(205), 3, V(207)))
         e(I("v_lshrrev_b32", V(202), 6, V(0)))
         e(I("s_nop", 1))
         e(I("v_readfirstlane_b32", S(20), V(202)))           # wave
@@ -119,7 +124,11 @@ def cases():
     XOR = lambda u, k: I("v_xor_b32", V(r(u, k)), 4 + k, V(200))
     LSA = lambda u, k: I("v_lshl_add_u32", V(r(u, k)), V(r(u, k)), 4, V(201))
     DSW = lambda u, k: I("ds_write_b64", V(201), V(64 + 2 * ((8 * u + k) % 16), 2), offset=1024 * ((8 * u + k) % 16))
-    solo = {"acr8": [ACR] * 8, "mul8": [MUL] * 8, "cvt8": [CVT] * 8, "xor8": [XOR] * 8, "lsa8": [LSA] * 8, "dsw8": [DSW] * 8,
+    # stores of the epilogue (no MFMA): whole 256-byte rows, 4 rows per instruction (what the kernel does after transposing through
+    # LDS) against the accumulator layout stored directly: 32 rows x 16 bytes per instruction.  V(206) / V(207): lane offsets
+    STR = lambda u, k: I("buffer_store_dwordx4", V(64 + 4 * ((8 * u + k) % 8), 4), V(206), S(8, 4), 0, offen=1, offset=1024 * ((8 * u + k) % 4))
+    STS = lambda u, k: I("buffer_store_dwordx2", V(64 + 2 * ((8 * u + k) % 16), 2), V(207), S(8, 4), 0, offen=1, offset=16 * ((8 * u + k) % 16))
+    solo = {"st_rows8": [STR] * 8, "st_scat8": [STS] * 8, "acr8": [ACR] * 8, "mul8": [MUL] * 8, "cvt8": [CVT] * 8, "xor8": [XOR] * 8, "lsa8": [LSA] * 8, "dsw8": [DSW] * 8,
             "fma8": [FMA] * 8, "exp8": [EXP] * 8, "acr_mul": [ACR, MUL] * 4, "mul_cvt": [MUL, CVT] * 4, "pk8": [PKA] * 8,
             "dsr8": [DSR] * 8, "mix": [ACR, MUL, CVT, XOR, ACR, MUL, LSA, DSW]}
     for nm, pat in solo.items():
