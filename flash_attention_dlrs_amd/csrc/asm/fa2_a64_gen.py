@@ -57,7 +57,7 @@ V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), acc
 V_NINF = 231              # causal: -inf (a literal would be the second constant-bus operand beside VCC)
 NINF = V(V_NINF)
 V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
-V_LSV = (234, 235)        # scratch (Q prefetch experiments)
+V_LSV = (234, 235)        # [0]: read-back address of the epilogue; [1] = V_PM[5] in the causal kernels
 V_MSV = (236, 237)        # running maximum of the finished job
 V_ONES = 244              # 4 registers: the 0 / 1 A operand of the row-sum MFMA (v_mfma_f32_16x16x32)
 V_LACC = (248, 252)       # row-sum accumulators of the two query blocks (4 registers each; register 0 = the lane's own row)
@@ -129,7 +129,7 @@ NSLOT = 24
 
 
 class Gen:
-    def __init__(self, dtype="bf16", causal=False, name=None, nexp_b=8, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
+    def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
                  caps=(5, 24)):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
@@ -139,7 +139,6 @@ class Gen:
         self.atmp_regs = (V_T[8], V_T[9])
         self.prog: list[Inst] = []
         self.uid = 0
-        self.nexp_b = nexp_b
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
@@ -525,24 +524,6 @@ class Gen:
         return out
 
     # ------------------------------------------------------------------ the two phases
-    def interleave(self, mfmas, fillers):
-        """fillers: list of (position, [insts]); a filler at position x goes after MFMA floor(x) (x < 0: before MFMA 0)"""
-        fillers = sorted(enumerate(fillers), key=lambda kv: (kv[1][0], kv[0]))
-        out, fi = [], 0
-        n = len(fillers)
-        while fi < n and fillers[fi][1][0] < 0:
-            out += fillers[fi][1][1]
-            fi += 1
-        for k, m in enumerate(mfmas):
-            out.append(m)
-            while fi < n and fillers[fi][1][0] < k + 1:
-                out += fillers[fi][1][1]
-                fi += 1
-        while fi < n:
-            out += fillers[fi][1][1]
-            fi += 1
-        return out
-
     def qk_mfmas(self, Y, cinit=None):
         """S^T(next) chains g = 2 qb + kb into score buffer Y.  cinit[g]: None -> C = 0, Reg -> C operand of the first MFMA"""
         out = []
@@ -557,17 +538,6 @@ class Gen:
             d = V(Y + 16 * g, 16)
             c = d if ks else (cinit[g] if cinit and cinit[g] is not None else 0)
             out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}"))
-        return out
-
-    def pv_mfmas(self, X):
-        """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep); P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s"""
-        out = []
-        for kstep in range(4):
-            kb, s = kstep >> 1, kstep & 1
-            for db in range(4):
-                for qb in range(2):
-                    p = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), p, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}"))
         return out
 
     def v_reads(self, buf):
