@@ -268,21 +268,32 @@ def main():
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # The timed region: exactly K steps between two HIP events on the stream the kernel is launched on (torch's current
+    # stream).  One event PAIR PER STEP, as in round 1, put two marker packets between consecutive launches -- 9.5 us of
+    # idle GPU per 457 us kernel, i.e. the measurement cost 2 % of `value`; the average launch duration is the bracket
+    # divided by K (it includes the launch-to-launch gap, so it can only overstate the kernel).  Per-launch events for
+    # the median / minimum run in a second, untimed pass of the same K steps.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
     t0 = time.perf_counter()
-    for s, e in ev:  # HIP events on the stream the kernel is launched on (torch's current stream)
-        s.record()
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        e.record()
+    ev1.record()
     sync_all()
     el = time.perf_counter() - t0
     if grouped:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
+    kern_avg = ev0.elapsed_time(ev1) / args.steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for s, e in ev:
+        s.record()
+        step()
+        e.record()
+    torch.cuda.synchronize(dev)
     kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    kern_avg = sum(kern_ms) / len(kern_ms)
 
     F = flops(c)
     ms_per_step = el * 1e3 / args.steps
