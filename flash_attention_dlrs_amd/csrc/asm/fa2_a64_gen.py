@@ -130,7 +130,7 @@ NSLOT = 24
 
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
-                 caps=(5, 24)):
+                 caps=(5, 24), split=False):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
@@ -143,6 +143,12 @@ class Gen:
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
         self.caps = caps       # fillers / issue cycles a gap behind a 32x32x16 MFMA may carry in the softmax plan
+        # causal row map "split": wave w owns the 32-row blocks w (qb 0) and w + 4 (qb 1) of the job's 256 rows instead of
+        # 2 w and 2 w + 1.  Diagonal tile j (key blocks 2 j, 2 j + 1) is then hidden from query block 0 of EVERY wave for
+        # j >= 2 and fully visible to query block 1 for j < 2: the job's last steps run on one query block (half the MFMAs)
+        # for all four waves instead of on both for a shrinking set of waves -- see build()
+        self.split = bool(split) and causal
+        self.cls = None        # split seam bodies: "low" (waves 0, 1) / "high" (waves 2, 3) while their code is generated
         self.ragged = ragged   # N is not a multiple of 256: range-checked descriptors, every offset in the VGPR operand, masked key tail
         assert not (ragged and stamps), "the ragged kernels use the stamps' temporaries as address registers"
         self.vread_double = vread_double   # phase-A gaps that carry two V transposed reads (the last read sits in gap 31 - this)
@@ -462,9 +468,10 @@ class Gen:
     def k_promote(self):
         """next job -> current job"""
         self.e(I("s_mov_b32", S_B, S_NB), I("s_mov_b32", S_HH, S_NHH), I("s_mov_b32", S_QI, S_NQI), I("s_mov_b32", S_NT, S_NNT),
-               # query rows of this wave: qrow[qb] = 256 qi + 64 wave + 32 qb
-               I("s_lshl_b32", S_T[0], S_QI, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_QROW[0], S_T[0], S_T[1]),
-               I("s_add_u32", S_QROW[1], S_QROW[0], 32))
+               # query rows of this wave: qrow[qb] = 256 qi + 64 wave + 32 qb  (split row map: 256 qi + 32 wave + 128 qb)
+               I("s_lshl_b32", S_T[0], S_QI, 8), I("s_lshl_b32", S_T[1], S_WAVE, 5 if self.split else 6),
+               I("s_add_u32", S_QROW[0], S_T[0], S_T[1]),
+               I("s_add_u32", S_QROW[1], S_QROW[0], 128 if self.split else 32))
 
     # ------------------------------------------------------------------ LDS-DMA
     def dma_piece(self, which, piece, buf):
@@ -495,7 +502,7 @@ class Gen:
         128 bytes: coalesced, ~25 cycles of issue each; the same rows fetched straight into the MFMA operand layout -- 32 rows x
         32 bytes per instruction -- cost ~210 cycles per load).  Returns (descriptor / offset setup, [pieces])"""
         setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh, S_QSN)
-        setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
+        setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 5 if self.split else 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
                   I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
                   I("s_lshl_b32", S_T[3], S_QSN, 3),                    # 8 rows
                   I("s_lshl_b32", S_T[4], S_WAVE, 14), I("s_add_u32", S_T[4], S_T[4], EPI)]
@@ -505,6 +512,9 @@ class Gen:
             for half in range(2):
                 pc = []
                 so = S_T[2]
+                if self.split and R == 4 and not half:
+                    # split row map: the second query block starts 128 rows behind the first (96 = 12 x 8 rows further on)
+                    pc += [I("s_mul_i32", S_X2, S_T[3], 12), I("s_add_u32", S_T[2], S_T[2], S_X2)]
                 if half:
                     so = S_T[5]
                     pc.append(I("s_add_u32", so, S_T[2], 128))
@@ -524,8 +534,9 @@ class Gen:
         return out
 
     # ------------------------------------------------------------------ the two phases
-    def qk_mfmas(self, Y, cinit=None):
-        """S^T(next) chains g = 2 qb + kb into score buffer Y.  cinit[g]: None -> C = 0, Reg -> C operand of the first MFMA"""
+    def qk_mfmas(self, Y, cinit=None, qbs=(0, 1)):
+        """S^T(next) chains g = 2 qb + kb into score buffer Y.  cinit[g]: None -> C = 0, Reg -> C operand of the first MFMA.
+        qbs: the query blocks whose chains are computed -- the others' MFMAs are None in the returned list (emit_phase)"""
         out = []
         if "qk_chain_order" in self.abl:     # (the round's first order: one chain after the other)
             order = [(g, ks) for g in range(4) for ks in range(8)]
@@ -537,7 +548,7 @@ class Gen:
             qb, kb = g >> 1, g & 1
             d = V(Y + 16 * g, 16)
             c = d if ks else (cinit[g] if cinit and cinit[g] is not None else 0)
-            out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}"))
+            out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}") if qb in qbs else None)
         return out
 
     def v_reads(self, buf):
@@ -743,7 +754,20 @@ class Gen:
             return [I(self.cvt, V(Sb + 16 * g + j), V(Sb + 16 * g + 2 * j), V(Sb + 16 * g + 2 * j + 1), tag=f"cvt g{g} {j}")]
         raise KeyError(kind)
 
-    def tile_fill(self, Sb, lo, hi, init, masks=None, abl=()):
+    @staticmethod
+    def op_qb(kind, payload):
+        """query block a placed softmax operation belongs to (None: not tied to one)"""
+        if kind in ("mx", "cv"):
+            return payload[0] >> 1
+        if kind == "dec":
+            return payload[0]
+        if kind in ("f", "e"):
+            return payload >> 5
+        if kind == "ms":
+            return payload
+        return None
+
+    def tile_fill(self, Sb, lo, hi, init, masks=None, abl=(), qbs=(0, 1)):
         """[(gap - lo, [insts], is_exp)] of the tile's operations with lo <= tau < hi.  masks: causal (jd, cond): the tile is
         diagonal tile jd of its job (when cond = (sgpr, value) holds, if given).  A job's first tile (init) gets its scores
         masked up front -- the tests of score group g go in front of its first row-maximum operation; every other diagonal
@@ -758,10 +782,18 @@ class Gen:
         plan = self.tile_plan(init)
         if lazy is not None:
             lz = self.LAZY_TAU
-            plan = sorted(plan + [(lz["ms0"], "ms", 0), (lz["ms1"], "ms", 1), (lz["mr"], "mr", None)] +
-                          ([] if tail else [(lz["pm"], "pm", None)]), key=lambda x: x[0])
+            if self.split and not tail:
+                # split row map: a hidden (tile, query block) is not computed at all -- no running-maximum swap ('ms' / 'mr');
+                # the packed-P masking only where this body's waves sit on the tile's diagonal and the block is computed
+                pm = self.cls is not None and (jd >> 1) in qbs and self.cls == ("low", "high")[jd & 1]
+                plan = sorted(plan + ([(lz["pm"], "pm", None)] if pm else []), key=lambda x: x[0])
+            else:
+                plan = sorted(plan + [(lz["ms0"], "ms", 0), (lz["ms1"], "ms", 1), (lz["mr"], "mr", None)] +
+                              ([] if tail else [(lz["pm"], "pm", None)]), key=lambda x: x[0])
         for t, kind, payload in plan:
             if not (lo <= t < hi):
+                continue
+            if self.op_qb(kind, payload) is not None and self.op_qb(kind, payload) not in qbs:
                 continue
             if ("no_" + kind) in abl or (kind == "dec" and payload[1] >= 3 and "no_fire" in abl):
                 continue   # timing-only ablations (diagnostic build)
@@ -793,6 +825,17 @@ class Gen:
             return [I("v_mov_b32", V(Y + 16 + r), NINF) for r in range(16)]
         return []
 
+    def group_mask_ops(self, Y, g, what):
+        """-inf into the scores of group g: what = "tri" (key block == query block: keys behind the query) or "all".
+        Register r of a group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i"""
+        if what == "all":
+            return [I("v_mov_b32", V(Y + 16 * g + r), NINF) for r in range(16)]
+        out = []
+        for r in range(16):
+            key = (r & 3) + 8 * (r >> 2)
+            out += [I("v_cmp_ge_i32", VCC, V(V_IMH), key), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
+        return out
+
     def mask_lazy(self, Sb, kind, payload, lazy):
         """Diagonal tiles other than a job's first are not masked before the softmax: the row maxima are taken over all 64 keys
         (a masked key can only RAISE a maximum: harmless unless it fires the deferred-maximum rescale, and that path --
@@ -803,6 +846,20 @@ class Gen:
                 query block, so that every exp2(s c - m) is 0 and nothing fires;  'mr' puts the maximum back.
         Both are in line, wave-uniform selects instead of branches (a taken branch costs ~25 cycles at one wave per SIMD)."""
         jd, cond = lazy
+        if self.split:
+            # every wave of this body sits on the diagonal of tile jd (tile_fill adds 'pm' only there): the even wave has
+            # pattern D0 on query block qa = jd >> 1 (key block 0: triangle, key block 1: hidden), the odd one D1 (key block 0
+            # visible, key block 1: triangle).  D0 in line, D1 out of line (a taken branch costs what eight VALU operations do)
+            assert kind == "pm"
+            qa = jd >> 1
+            g0, g1 = 2 * qa, 2 * qa + 1
+            l_d1, l_back, l_skip = self.lab("pmask_d1"), self.lab("pmask_back"), self.lab("pmask_skip")
+            self.ool.append([label(l_d1)] + [I("v_and_b32", V(Sb + 16 * g1 + j), V(Sb + 16 * g1 + j), V(V_PM[j])) for j in range(8)] +
+                            [I("s_branch", Label(l_back))])
+            head = [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_skip))] if cond is not None else []
+            return head + [I("s_bitcmp1_b32", S_WAVE, 0), I("s_cbranch_scc1", Label(l_d1))] + \
+                [I("v_and_b32", V(Sb + 16 * g0 + j), V(Sb + 16 * g0 + j), V(V_PM[j])) for j in range(8)] + \
+                [I("v_mov_b32", V(Sb + 16 * g1 + j), 0) for j in range(8)] + [label(l_back)] + ([label(l_skip)] if cond is not None else [])
         if kind == "pm":
             l_pm, l_back = self.lab("pmask"), self.lab("pmask_back")
             blk = [label(l_pm)]
@@ -864,6 +921,24 @@ class Gen:
         l_plain = self.lab("fire_plain")
         a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
         blk = []
+        if self.split:
+            # only query block jd >> 1 has waves on the diagonal of tile jd: waves 2 p (pattern D0) and 2 p + 1 (D1), p = jd & 1
+            if qb != jd >> 1:
+                return []
+            p2 = 2 * (jd & 1)
+            l_d1, l_max = self.lab("fire_d1"), self.lab("fire_max")
+            if cond is not None:
+                blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_plain))]
+            blk += [I("s_cmp_eq_u32", S_WAVE, p2 + 1), I("s_cbranch_scc1", Label(l_d1)),
+                    I("s_cmp_eq_u32", S_WAVE, p2), I("s_cbranch_scc0", Label(l_plain))]
+            blk += self.group_mask_ops(Sb, 2 * qb, "tri") + self.group_mask_ops(Sb, 2 * qb + 1, "all") + [I("s_branch", Label(l_max))]
+            blk += [label(l_d1)] + self.group_mask_ops(Sb, 2 * qb + 1, "tri") + [label(l_max)]
+            for g, mx in ((2 * qb, a), (2 * qb + 1, b)):
+                y = lambda r: V(Sb + 16 * g + r)
+                blk += [I("v_max3_f32", mx, y(0), y(1), y(2))] + [I("v_max3_f32", mx, mx, y(2 * j + 1), y(2 * j + 2)) for j in range(1, 7)] + \
+                    [I("v_max_f32", mx, mx, y(15))]
+            blk += [I("v_max_f32", a, a, b), I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b), label(l_plain)]
+            return blk
         if cond is not None:
             blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_plain))]
         blk += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc0", Label(l_plain))]
@@ -883,6 +958,27 @@ class Gen:
         Returns the in-line tests for score group g (in front of its first row-maximum operation); the masking itself runs
         out of line.  The branch sits where that row-maximum operation is legal, i.e. the MFMA -> VALU wait states have passed
         (check.check_branch_targets verifies it on the built program)."""
+        if self.split:
+            # waves 2 p / 2 p + 1 (p = jd & 1) carry patterns D0 / D1 on query block jd >> 1 (see mask_lazy); a block wholly
+            # hidden from a wave is not computed at all by the split bodies
+            l_back = self.lab("mask_back")
+            qb, kb = g >> 1, g & 1
+            if qb != jd >> 1:
+                return []
+            p2 = 2 * (jd & 1)
+            tests = []
+            l_d0 = self.lab("mask_d0")
+            self.ool.append([label(l_d0)] + self.group_mask_ops(Y, g, "tri" if kb == 0 else "all") + [I("s_branch", Label(l_back))])
+            tests += [I("s_cmp_eq_u32", S_WAVE, p2), I("s_cbranch_scc1", Label(l_d0))]
+            if kb == 1:
+                l_d1 = self.lab("mask_d1")
+                self.ool.append([label(l_d1)] + self.group_mask_ops(Y, g, "tri") + [I("s_branch", Label(l_back))])
+                tests += [I("s_cmp_eq_u32", S_WAVE, p2 + 1), I("s_cbranch_scc1", Label(l_d1))]
+            if cond is None:
+                return tests + [label(l_back)]
+            l_tests = self.lab("mask_tests")
+            self.ool.append([label(l_tests)] + tests + [I("s_branch", Label(l_back))])
+            return [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_tests)), label(l_back)]
         l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
         tests = []
         eq_ops = self.score_mask_ops(Y, g)
@@ -907,19 +1003,35 @@ class Gen:
     def emit_phase(self, mfmas, gaps):
         """gaps[k] = fillers behind MFMA k: (order, [insts]) with order 0 = LDS / DMA loads, 1 = exp2, 2 = the rest, 3 = last"""
         out = []
-        for k, m in enumerate(mfmas):
-            out.append(m)
+        kept = [k for k, m in enumerate(mfmas) if m is not None]
+        if len(kept) == len(mfmas):
+            for k, m in enumerate(mfmas):
+                out.append(m)
+                for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
+                    out += ins
+            return out
+        # some MFMAs are left out (a query block the tile is hidden from): the fillers of the original gaps, each gap's group
+        # kept whole and in the original order, are spread over the remaining MFMAs in proportion -- a filler never moves in
+        # front of an MFMA it followed (check.fix pads what lands too close behind one)
+        n, nk = len(mfmas), len(kept)
+        assert nk > 0, "a phase without MFMAs is emitted by its caller"
+        buckets = [[] for _ in range(nk)]
+        for k in range(n):
             for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
-                out += ins
+                buckets[min(k * nk // n, nk - 1)] += ins
+        for idx, k in enumerate(kept):
+            out.append(mfmas[k])
+            out += buckets[idx]
         return out
 
-    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=(), cur_masks=None, extra=()):
+    def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=(), cur_masks=None, extra=(),
+                cur_qbs=(0, 1), nxt_qbs=(0, 1)):
         """A(t), t4 = t & 3: QK^T(t+1) -> S[1-p]  ||  V(t) reads from VB[t % R]  ||  the late softmax operations of tile t (on S[p])
         ||  the early ones of tile t+1 (on S[1-p])"""
         p = t4 & 1
         X, Y = SBUF[p], SBUF[1 - p]
         abl = self.abl if steady else set()
-        mf = self.qk_mfmas(Y) if with_qk else []
+        mf = self.qk_mfmas(Y, qbs=nxt_qbs) if with_qk else []
         gaps = {}
         add = lambda k, order, ins: gaps.setdefault(min(max(int(k), 0), 31), []).append((order, ins))
         if cur:
@@ -927,10 +1039,10 @@ class Gen:
                 for k, ins in enumerate(self.v_reads(t4 % self.R)):
                     add(self.a_vread_gap(k), 0, [ins])
             if "nofinish" not in abl:
-                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False, cur_masks, abl=abl):
+                for k, ins, is_exp in self.tile_fill(X, 32 + self.NB, self.T_END, False, cur_masks, abl=abl, qbs=cur_qbs):
                     add(k, 1 if is_exp else 2, ins)
         if nxt and "nostart" not in abl:
-            for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks, abl=abl):
+            for k, ins, is_exp in self.tile_fill(Y, 0, 32, nxt_init, masks, abl=abl, qbs=nxt_qbs):
                 add(k, 1 if is_exp else 2, ins)
         for g, ins in extra:
             add(g, 2, ins)
@@ -941,7 +1053,7 @@ class Gen:
             return [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
         return self.emit_phase(mf, gaps)
 
-    def pv_mfmas(self, X):
+    def pv_mfmas(self, X, qbs=(0, 1)):
         """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep) with P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s; behind each
         k-step the row sums of its two P fragments on the matrix pipe: a 16x16x32 MFMA against the 0 / 1 operand V_ONES puts
         the 16-key sum of the lane's own query into register 0 of V_LACC[qb] (fa2_mfma16h.hip, FA2_H_MSUM, has the lane maths)"""
@@ -952,14 +1064,16 @@ class Gen:
             for db in range(4):
                 for qb in range(2):
                     pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), pf, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}"))
+                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), pf, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}")
+                               if qb in qbs else None)
             for qb in range(2):
                 pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                out.append(I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}"))
+                out.append(I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}")
+                           if qb in qbs else None)
         return out
 
     def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
-                pre=(), early=(), late=(), masks=None, own_gaps=None, post=()):
+                pre=(), early=(), late=(), masks=None, own_gaps=None, post=(), cur_qbs=(0, 1), nxt_qbs=(0, 1)):
         """B(t), t4 = t & 3: P.V(t) and the row sums of P(t) from S[p]  ||  the middle softmax operations of tile t+1 (on S[1-p])
         ||  K(t+2) reads from KB[(t+2) % R]  ||  LDS-DMA V(t+dv) -> VB[(t+dv) % R], K(t+dk) -> KB[(t+dk) % R].
         pre: instructions ahead of the phase;  early: scalar work / register loads spread over the first gaps;
@@ -967,7 +1081,7 @@ class Gen:
         p = t4 & 1
         X, Y = SBUF[p], SBUF[1 - p]
         abl = self.abl if steady else set()
-        mf = self.pv_mfmas(X) if with_pv else []
+        mf = self.pv_mfmas(X, qbs=cur_qbs) if with_pv else []
         NB = self.NB
         gaps = {}
         add = lambda k, order, ins: gaps.setdefault(min(max(int(k), 0), NB - 1), []).append((order, ins))
@@ -1008,7 +1122,7 @@ class Gen:
             add(g - 1, 3, setup)
             add(g, 0, [load])
         if nxt and "nostart" not in abl:
-            for k, ins, is_exp in self.tile_fill(Y, 32, 32 + NB, nxt_init, masks, abl=abl):
+            for k, ins, is_exp in self.tile_fill(Y, 32, 32 + NB, nxt_init, masks, abl=abl, qbs=nxt_qbs):
                 add(k, 1 if is_exp else 2, ins)
         if not mf:
             body = [x for k in sorted(gaps) for _, ins in sorted(gaps[k], key=lambda x: x[0]) for x in ins]
@@ -1049,9 +1163,10 @@ class Gen:
 
     def step(self, t4, a_pre=(), **kw):
         """one tile step, t4 = t & 3"""
-        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady", "dma", "cur_masks", "extra")}
+        ka = {k: v for k, v in kw.items() if k in ("with_qk", "cur", "nxt", "nxt_init", "steady", "dma", "cur_masks", "extra",
+                                                   "cur_qbs", "nxt_qbs")}
         kb = {k: v for k, v in kw.items() if k in ("with_pv", "nxt", "nxt_init", "with_kread", "with_dma", "steady", "pre", "early", "late",
-                                                   "own_gaps", "post")}
+                                                   "own_gaps", "post", "cur_qbs", "nxt_qbs")}
         if kw.get("masks") is not None:   # the masking tests of a score group sit in front of its first row-maximum operation
             ka["masks"] = kw["masks"]
             kb["masks"] = kw["masks"]
@@ -1268,11 +1383,43 @@ class Gen:
                     # the job's last tile: its running maxima are put aside for the epilogue before the next job's first
                     # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
                     save = [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
-                    if cm or self.ragged:   # (behind the tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
+                    if (cm and not self.split) or (self.ragged and not cm):   # (behind the tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
                         kw.update(nxt_init=True, extra=list(kw.get("extra", ())) + [(self.LAZY_TAU["mr"] - self.PERIOD + 1, save)])
                     else:
                         kw.update(nxt_init=True, a_pre=save)
                 e(self.stamp(16 + st))
+                if self.split:
+                    # split row map (wave w: 32-row blocks w and w + 4).  Diagonal tile j -- key blocks 2 j, 2 j + 1 -- against
+                    # query block 0 (row block w): hidden for w < 2 j, on the diagonal for w = 2 j (D0) / 2 j + 1 (D1), visible
+                    # above; against query block 1 (row block w + 4): the same with w + 4.  So tile 0: everything runs (waves
+                    # 0 / 1 mask block 0), tile 1: block 0 only on waves 2, 3 (which mask it), tile 2: block 1 only (waves 0 / 1
+                    # mask), tile 3: block 1 on waves 2, 3 only (which mask).  Step st finishes tile st and starts tile st + 1:
+                    # two bodies per step, waves 0-1 ("low") out of line, waves 2-3 ("high") in line, each with only the MFMAs
+                    # and softmax operations of the blocks it needs -- 216 MFMA slots on the critical path instead of 288.
+                    cur_q = (((0, 1), (0, 1)), ((1,), (0, 1)), ((1,), (1,)), ((), (1,)))[st]
+                    nxt_q = (((1,), (0, 1)), ((1,), (1,)), ((), (1,)), ((0, 1), (0, 1)))[st]
+                    if st == 3 and "a_pre" not in kw:
+                        pass
+                    l_low, l_join = self.lab("low"), self.lab("low_join")
+                    e(I("s_cmp_lt_u32", S_WAVE, 2), I("s_cbranch_scc1", Label(l_low)))
+                    for ci, cls in ((1, "high"), (0, "low")):
+                        ckw = dict(kw)
+                        cq, nq_ = cur_q[ci], nxt_q[ci]
+                        ckw.update(cur_qbs=cq or (0, 1), nxt_qbs=nq_ or (0, 1))
+                        if not cq:
+                            ckw.update(cur=False, with_pv=False)
+                        if not nq_:
+                            ckw.update(with_qk=False, nxt=False)
+                        self.cls = cls
+                        if cls == "high":
+                            e(self.step(st, early=early, pre=pre, **ckw), label(l_join))
+                        else:
+                            body, self.prog = self.prog, []
+                            e(label(l_low), self.step(st, early=early, pre=pre, **ckw), I("s_branch", Label(l_join)))
+                            self.ool.append(self.prog)
+                            self.prog = body
+                        self.cls = None
+                    continue
                 lean = cm and st >= 1 and "nolean" not in self.abl
                 half = cm and st < 3 and "nolean" not in self.abl
                 if lean:
@@ -1364,7 +1511,7 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # Measured that way on c3 causal: nolean -1.0 %; plan capacities (6, 26) / (6, 24) / (5, 26) / (5, 25) +-0.3 %, (7, 28) -1.7 %;
 # one-chain-after-the-other QK^T order -0.2 %; zero-operand K and V^T fragments for hidden tiles +0.4 % / 0 (dropped for the
 # lean bodies); V reads doubled up in 2 instead of 4 gaps 0.
-VARIANTS = {"base": dict(), "nolean": dict(abl=("nolean",)), "chain": dict(abl=("qk_chain_order",)), "caps626": dict(caps=(6, 26))}
+VARIANTS = {"base": dict(), "nolean": dict(abl=("nolean",)), "split": dict(split=True)}
 
 
 def module_text(gens):
