@@ -49,7 +49,7 @@ V_T = tuple(range(210, 220))     # temporaries (V_T[2] = v212 is 4-aligned: a ze
 V_QOFF = 220              # (unused)
 V_LANE = 221
 V_EW = 222                # epilogue LDS write base (row i, +8h)
-V_ESW = 223               # epilogue swizzle term swz(i)
+V_ESW = 223               # (unused)
 V_ER = 224                # epilogue LDS read base
 V_EO = 225                # epilogue global store lane offset (os_n)
 V_L2 = 226                # L store lane offset
@@ -122,6 +122,7 @@ VBASE = 32768
 VB = (0, 16384)                  # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
 EPI = 65536                      # + 16384 * wave: the wave's private 64 x 256-byte slice: the next job's Q rows land here by
                                  # LDS-DMA (K-tile image) on their way to a[128:191]; later the job's O rows leave through it
+EPI_ROW = 272                    # (= 256 + 16, formed with shifts in k_setup) byte stride of an O row in the slice during the epilogue (k_setup)
 LDS_TOTAL = 131072
 
 KARG_SIZE = 192
@@ -130,7 +131,7 @@ NSLOT = 24
 
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
-                 caps=(5, 24), split=False):
+                 caps=(5, 24), split=True):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
@@ -347,16 +348,17 @@ class Gen:
           I("v_add_u32", V(V_DQO), t2, t3),
           I("s_lshl_b32", S_T[0], S_WAVE, 14), I("s_add_u32", S_T[0], S_T[0], EPI),
           I("v_add_u32", V(V_QRE), S_T[0], V(V_KRE)), I("v_add_u32", V(V_QRO), S_T[0], V(V_KRO)))
-        # ---- epilogue: write base EPI + 16384 wave + 256 i + 8 h; swizzle term ((i & 3) << 2) | ((i >> 2) & 3)
+        # ---- epilogue: the wave's slice holds a query block's 32 O rows at a stride of EPI_ROW = 272 bytes (256 + 16: the
+        #      8-byte writes of a column group and the 16-byte row reads both spread over all banks, and every address is a lane
+        #      base plus an immediate).  Write base EPI + 16384 wave + 272 i + 8 h
         e(comment("epilogue lane constants"),
           I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane),
-          I("v_lshlrev_b32", t1, 8, t0), I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1),
-          I("v_and_b32", t1, 3, t0), I("v_lshlrev_b32", t1, 2, t1), I("v_bfe_u32", t2, t0, 2, 2), I("v_or_b32", t1, t1, t2),
-          I("v_mov_b32", V(V_ESW), t1))
-        # read-back: a = lane >> 4, ec = lane & 15: base + 256 a + ((ec ^ (a << 2)) << 4); store offset a * os_n + 16 ec
+          I("v_lshlrev_b32", t1, 8, t0), I("v_lshl_add_u32", t1, t0, 4, t1),    # 272 i
+          I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1))
+        # read-back: a = lane >> 4, ec = lane & 15: base + 272 a + 16 ec (+ 4 x 272 k: row 4 k + a); store offset a * os_n + 16 ec
         e(I("v_lshrrev_b32", t0, 4, lane), I("v_and_b32", t1, 15, lane),
-          I("v_lshlrev_b32", t2, 2, t0), I("v_xor_b32", t2, t2, t1), I("v_lshlrev_b32", t2, 4, t2),
-          I("v_lshl_add_u32", t2, t0, 8, t2), I("v_add_u32", V(V_ER), S_T[0], t2),
+          I("v_lshlrev_b32", t2, 8, t0), I("v_lshl_add_u32", t2, t0, 4, t2),    # 272 a
+          I("v_lshl_add_u32", t2, t1, 4, t2), I("v_add_u32", V(V_ER), S_T[0], t2),
           I("v_mul_lo_u32", t2, t0, S_OSN), I("v_lshl_add_u32", V(V_EO), t1, 4, t2),
           I("v_and_b32", t0, 31, lane), I("v_lshlrev_b32", V(V_L2), 1, t0))
         if self.stamps:
@@ -1215,8 +1217,6 @@ class Gen:
         # waits on its predecessor.
         rows = [V(SBUF[1] + 4 * k, 4) for k in range(8)]
         tset = [[V(SBUF[1] + 32 + 16 * sidx + k) for k in range(16)] for sidx in range(2)]
-        aset = [[V(V_T[6]), V(V_T[7]), V(V_T[8]), V(V_T[9])], [V(V_MX[0][0]), V(V_MX[0][1]), V(V_MX[1][0]), V(V_MX[1][1])]]
-        addr2 = V(V_LSV[0])   # (not V_CO: the rescale factors must stay 1.0 between firings)
 
         def weave(*lists):
             out, idx = [], [0] * len(lists)
@@ -1249,30 +1249,23 @@ class Gen:
         def read_back():
             out = []
             for k in range(8):   # whole rows: row 4 k + a
-                if k & 3:
-                    out.append(I("v_xor_b32", addr2, V(V_ER), (k & 3) << 4))
-                    src_a = addr2
-                else:
-                    src_a = V(V_ER)
-                out.append(I("ds_read_b128", rows[k], src_a, offset=1024 * k))
+                out.append(I("ds_read_b128", rows[k], V(V_ER), offset=4 * EPI_ROW * k))
             return out
 
         for qb in range(2):
             stages = []  # per batch: [reads, muls + address, packs, writes]
             for db in range(4):
-                tm, ad = tset[db & 1], aset[db & 1]
+                tm = tset[db & 1]
                 src = A_O(qb, db)
                 rd = [I("v_accvgpr_read_b32", tm[k], src.sub(k)) for k in range(16)]
                 # (packed fp32 multiplies: half the instructions; beside an MFMA they would cost ~50 cycles each, here the
                 # matrix pipe is idle and every VALU instruction takes the same ~5.8 cycles at one wave per SIMD)
                 mu = [I("v_pk_mul_f32", V(tm[k].idx, 2), V(tm[k].idx, 2), V(inv[qb].idx, 2), op_sel_hi=(1, 0)) for k in range(0, 16, 2)]
-                ax = [I("v_xor_b32", ad[g4], 4 * db + g4, V(V_ESW)) for g4 in range(4)]
-                al = [I("v_lshl_add_u32", ad[g4], ad[g4], 4, V(V_EW)) for g4 in range(4)]
                 cv = []
                 for g4 in range(4):
                     cv += [I(self.cvt, tm[4 * g4], tm[4 * g4], tm[4 * g4 + 1]), I(self.cvt, tm[4 * g4 + 1], tm[4 * g4 + 2], tm[4 * g4 + 3])]
-                wr = [I("ds_write_b64", ad[g4], V(tm[4 * g4].idx, 2)) for g4 in range(4)]
-                stages.append((rd, weave(mu, ax), weave(cv, al), wr))
+                wr = [I("ds_write_b64", V(V_EW), V(tm[4 * g4].idx, 2), offset=16 * (4 * db + g4)) for g4 in range(4)]
+                stages.append((rd, mu, cv, wr))
             # software pipeline over the four batches (two register sets): batch b + 1 is read while batch b is scaled, ...
             head = stages[0][0] + weave(stages[0][1], stages[1][0]) + stages[0][2] + stages[0][3]
             tail = weave(stages[1][1], stages[2][0]) + stages[1][2] + stages[1][3] + weave(stages[2][1], stages[3][0]) + \
@@ -1398,8 +1391,6 @@ class Gen:
                     # and softmax operations of the blocks it needs -- 216 MFMA slots on the critical path instead of 288.
                     cur_q = (((0, 1), (0, 1)), ((1,), (0, 1)), ((1,), (1,)), ((), (1,)))[st]
                     nxt_q = (((1,), (0, 1)), ((1,), (1,)), ((), (1,)), ((0, 1), (0, 1)))[st]
-                    if st == 3 and "a_pre" not in kw:
-                        pass
                     l_low, l_join = self.lab("low"), self.lab("low_join")
                     e(I("s_cmp_lt_u32", S_WAVE, 2), I("s_cbranch_scc1", Label(l_low)))
                     for ci, cls in ((1, "high"), (0, "low")):
@@ -1510,8 +1501,10 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # benchmarks/variants.py interleaves them in one process, which resolves +-0.3 % -- across gpurun calls boxes differ by 7 %).
 # Measured that way on c3 causal: nolean -1.0 %; plan capacities (6, 26) / (6, 24) / (5, 26) / (5, 25) +-0.3 %, (7, 28) -1.7 %;
 # one-chain-after-the-other QK^T order -0.2 %; zero-operand K and V^T fragments for hidden tiles +0.4 % / 0 (dropped for the
-# lean bodies); V reads doubled up in 2 instead of 4 gaps 0.
-VARIANTS = {"base": dict(), "nolean": dict(abl=("nolean",)), "split": dict(split=True)}
+# lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
+# lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
+# issued in the first gaps of the short steps: 0.
+VARIANTS = {"base": dict(), "nosplit": dict(split=False), "nosplit_nolean": dict(split=False, abl=("nolean",))}
 
 
 def module_text(gens):
@@ -1542,6 +1535,9 @@ def main(argv=None):
             gens.append(g)
     if args.stamps:  # timing-only ablations ride in the diagnostic code object
         g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite", stamps=True, abl=("lite",))
+        g.build()
+        gens.append(g)
+        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_nosplit", stamps=True, abl=("lite",), split=False)
         g.build()
         gens.append(g)
         for nm, abl in [("lite", ())] + list(ABLATIONS.items()):

@@ -21,11 +21,11 @@ ORACLE_DT = {"bf16": "bfloat16", "f16": "float16"}
 _PROGS = {}
 
 
-def prog(dtype, causal):
-    if (dtype, causal) not in _PROGS:
-        g = Gen(dtype, causal)
-        _PROGS[(dtype, causal)] = (g, g.build())
-    return _PROGS[(dtype, causal)]
+def prog(dtype, causal, split=True):
+    if (dtype, causal, split) not in _PROGS:
+        g = Gen(dtype, causal, split=split)
+        _PROGS[(dtype, causal, split)] = (g, g.build())
+    return _PROGS[(dtype, causal, split)]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -82,18 +82,20 @@ def test_emulated_kernel_frequent_rescales_across_jobs(oracle):
     assert not np.isnan(O).any() and np.abs(O - O_ref).max() <= O_TOL["bf16"]
 
 
-@pytest.mark.parametrize("dtype,thr", [("bf16", None), ("f16", None), ("bf16", 8.0)])
-def test_emulated_causal_diagonal_with_large_masked_scores(oracle, dtype, thr):
+@pytest.mark.parametrize("dtype,thr,split", [("bf16", None, True), ("f16", None, True), ("bf16", 8.0, True), ("bf16", None, False),
+                                             ("bf16", 8.0, False)])
+def test_emulated_causal_diagonal_with_large_masked_scores(oracle, dtype, thr, split):
     """the lazily masked diagonal tiles: keys a few positions AHEAD of their query carry scores far above every visible one
     (s = 40 .. 160 log2 units).  The row maxima are taken over them; that must neither leak into m (the firing path masks
-    exactly and takes the maxima again) nor into P (the packed-P masking), on the wave that sits on the diagonal, on the waves
-    below it (running maximum swapped for +inf) and in the steady loop's last trip (diagonal tile 0 of a longer job)."""
+    exactly and takes the maxima again) nor into P (the packed-P masking), on the waves that sit on the diagonal (patterns D0 /
+    D1 of the split row map, the product default) and in the steady loop's last trip (diagonal tile 0 of a longer job).
+    split = False: the contiguous row map kept as an A/B variant (waves below the diagonal: running maximum swapped for +inf)."""
     rng = np.random.default_rng(11)
     B, H, N = 1, 2, 768
     Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) * 0.5 for _ in range(3))
     for q, ahead, gain in ((5, 3, 2.0), (40, 20, 4.0), (100, 60, 8.0), (300, 1, 6.0), (517, 50, 3.0), (600, 100, 5.0), (767 - 64, 63, 8.0)):
         K[:, :, q + ahead] = gain * Q[:, :, q]        # masked for row q; visible (and large) only for rows >= q + ahead
-    _, p = prog(dtype, True)
+    _, p = prog(dtype, True, split)
     kw = dict(thr_override=thr) if thr is not None else {}
     O, L, _ = harness.run(p, Q, K, V, dtype=dtype, causal=True, nwg=1, **kw)
     rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
