@@ -1185,6 +1185,12 @@ class Gen:
         return out
 
     # ------------------------------------------------------------------ epilogue of the current job
+    def epilogue_descs(self):
+        """descriptors of the current job's O rows (S_SQ: the next job's Q rows are through by then) and L (S_NVRS: the next job's V
+        descriptor has moved to S_VRS): scalar work that rides in the gaps of the seam's last phase B instead of standing in
+        front of the epilogue"""
+        return self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH, S_OSN) + self.make_desc(S_NVRS, S_L, S_LSB, S_LSH, S_B, S_HH, 2)
+
     def k_epilogue(self):
         """1 / l (one Newton step), L = m + log2 l, O^T -> rows through the wave's LDS slice -> 16-byte row stores, O^T := 0.
         A workgroup's O tile is 64 KiB and the CU's vector-memory path takes 64 bytes per cycle: the row stores of the first
@@ -1193,8 +1199,8 @@ class Gen:
         e = self.e
         t = [V(x) for x in V_T]
         e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global; O^T := 0"))
-        e(self.make_desc(S_SQ, S_O, S_OSB, S_OSH, S_B, S_HH, S_OSN))
-        e(I("s_nop", 7))  # last P.V MFMAs -> accumulator reads (the descriptor arithmetic above counts as well)
+        # (the O and L descriptors of this job were formed in the seam's last phase B: epilogue_descs)
+        e(I("s_nop", 15))  # last P.V MFMAs -> accumulator reads
         l = [t[0], t[3]]
         m2 = [t[1], t[5]]
         inv = [t[2], t[4]]    # (even registers: they are read as the low word of an aligned 64-bit operand below)
@@ -1285,18 +1291,22 @@ class Gen:
         z = V(SBUF[1] + 32, 4)    # (the second block's temporaries: free again)
         e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
         e([I("v_mov_b32", z.sub(k), 0) for k in range(4)], I("s_nop", 1))
-        for qb in range(2):
-            for db in range(4):
-                e(I(self.mfma, A_O(qb, db), z, z, 0))
+        # (the wave can issue one of these every 32 cycles and one row store every ~75 with all four waves storing: interleaved,
+        # the stores hide the MFMAs; two MFMAs go first, under the read-back's LDS round trip)
+        zero = [I(self.mfma, A_O(qb, db), z, z, 0) for qb in range(2) for db in range(4)]
+        st1 = row_stores(1)
+        e(zero[0], zero[1])
         e(self.stamp_async(4))
         e(waitcnt(lgkmcnt=0))
-        e([x for grp in row_stores(1) for x in grp])
+        for k in range(8):
+            e(st1[k])
+            if k + 2 < 8:
+                e(zero[k + 2])
         e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the descriptor arithmetic below: it uses the stamp registers)
         # L store (lanes 0..31), in the I/O dtype: behind the row stores (they hold the vector-memory path for a while)
-        e(self.make_desc(S_SQ, S_L, S_LSB, S_LSH, S_B, S_HH, 2))
         e(I("s_lshr_b64", EXEC, EXEC, 32))
         for qb in range(2):
-            pre, st = self.buf_op("buffer_store_short", m2[qb], V(V_L2), S_SQ, S_T[0])
+            pre, st = self.buf_op("buffer_store_short", m2[qb], V(V_L2), S_NVRS, S_T[0])
             e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), pre, st)
         e(I("s_mov_b64", EXEC, -1))
         self.atmp_regs = (V_T[8], V_T[9])
@@ -1348,6 +1358,7 @@ class Gen:
                 self.make_desc(S_NVRS, S_V, S_VSB, S_VSH, S_NB, S_NHH, S_VSN)
             vpre = [I("s_mov_b32", S_VRS.sub(k), S_NVRS.sub(k)) for k in range(4)] + [I("s_mov_b32", S_VDMA, S_VW)]
             sk, sv = 4 - self.dk, 4 - self.dv      # seam step whose phase B streams the next job's first K / V tile
+            assert sk <= 2 and sv <= 2             # (step 3 re-uses S_SQ and S_NVRS for the epilogue's descriptors)
             qs_setup, qs_pieces = self.q_stage(S_NB, S_NHH, S_NQI)
             for st in range(4):
                 kw = dict(masks=((st + 1,) if st < 3 else (0, (S_NNT, 4))) if cm else None, cur_masks=(st,) if cm else None)
@@ -1373,6 +1384,7 @@ class Gen:
                 if st == 2:
                     early += self.q_reads()      # slice -> a[128:191] (Q was last read by this step's phase A)
                 if st == 3:
+                    early += self.epilogue_descs()
                     # the job's last tile: its running maxima are put aside for the epilogue before the next job's first
                     # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
                     save = [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
