@@ -158,6 +158,8 @@ int fa2_launch_a64(const Fa2Problem &p) {
             fa2_set_error("a64 experiments build: kernel %s not found", kn);
             return FA2_ERR_BAD_ARG;
         }
+        const char *th = getenv("FA2_A64_THR");    // the deferral threshold (log2 units), for A/B runs
+        if (th && *th) a.thr = (float)atof(th);
     }
 #endif
 #ifdef FA2_A64_STAMPS
