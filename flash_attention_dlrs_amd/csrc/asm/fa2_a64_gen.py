@@ -742,7 +742,7 @@ class Gen:
             exact = self.fire_exact(Sb, qb, lazy) if lazy is not None else []
             self.ool.append([label(l_fire)] + exact + [I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
                              I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
-                             I("s_mov_b32", S_FLAG, 1), I("s_branch", Label(l_back))])
+                             I("s_or_b32", S_FLAG, S_FLAG, 1 << qb), I("s_branch", Label(l_back))])
             return [I("s_cmp_lg_u64", S_FIRE[qb], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
         if kind == "f":
             e = payload
@@ -1135,16 +1135,21 @@ class Gen:
             # deferred rescale of O and the row sums by the factors the decisions of this step left (rare)
             l_rs, l_back = self.lab("rescale"), self.lab("rescale_back")
             body += [I("s_cmp_lg_u32", S_FLAG, 0), I("s_cbranch_scc1", Label(l_rs)), label(l_back)]
+            # (bit qb of S_FLAG: query block qb fired in this step -- only its accumulators are touched; packed multiplies: the
+            # matrix pipe is idle here.  f16 inputs fire a few times per job: P must stay below 65 504)
             blk = [label(l_rs), I("s_nop", 15)]
             tmp = [V(V_T[k]) for k in range(8)]
+            co = V(V_T[8], 2)      # (an even register: the factor is read as the low word of an aligned 64-bit operand)
             for qb in range(2):
+                l_skip = self.lab("rescale_skip")
+                blk += [I("s_bitcmp1_b32", S_FLAG, qb), I("s_cbranch_scc0", Label(l_skip)), I("v_mov_b32", co.sub(0), V(V_CO[qb]))]
                 for base in range(0, 64, 8):
                     regs = [A(qb * 64 + base + k) for k in range(8)]
                     blk += [I("v_accvgpr_read_b32", tmp[k], regs[k]) for k in range(8)]
-                    blk += [I("v_mul_f32", tmp[k], tmp[k], V(V_CO[qb])) for k in range(8)]
+                    blk += [I("v_pk_mul_f32", V(tmp[k].idx, 2), V(tmp[k].idx, 2), co, op_sel_hi=(1, 0)) for k in range(0, 8, 2)]
                     blk += [I("v_accvgpr_write_b32", regs[k], tmp[k]) for k in range(8)]
-                blk += [I("v_mul_f32", V(V_LACC[qb] + k), V(V_LACC[qb] + k), V(V_CO[qb])) for k in range(4)]
-                blk += [I("v_mov_b32", V(V_CO[qb]), 1.0)]
+                blk += [I("v_pk_mul_f32", V(V_LACC[qb] + k, 2), V(V_LACC[qb] + k, 2), co, op_sel_hi=(1, 0)) for k in (0, 2)]
+                blk += [I("v_mov_b32", V(V_CO[qb]), 1.0), label(l_skip)]
             blk += [I("s_mov_b32", S_FLAG, 0), I("s_nop", 3), I("s_branch", Label(l_back))]
             self.ool.append(blk)
         return body

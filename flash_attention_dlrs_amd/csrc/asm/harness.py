@@ -9,6 +9,8 @@ from .emu import Memory, Workgroup, bf16_to_f32, f32_to_bf16_rne
 from .fa2_a64_gen import KARG_SIZE, Gen
 
 LOG2E = 1.4426950408889634
+# deferral threshold of the running maximum (log2 units) the launcher passes (fa2_a64.hip): P <= 2^thr; f16 P must stay below 65 504
+A64_THR = {"bf16": 60.0, "f16": 15.5}
 
 
 def to_dt(x, dtype):
@@ -57,7 +59,7 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     total = nunit * nbh
     nwg = nwg or min(total, 256)
     sb, sh, sn = H * N * D * 2, N * D * 2, D * 2
-    thr = 60.0 if dtype == "bf16" else 12.0
+    thr = A64_THR[dtype]
     if thr_override is not None:
         thr = thr_override
     ka = pack_kargs([bufs[k][0] for k in "QKVOL"], (sb, sh) * 4 + (H * N * 2, N * 2), (sn,) * 4, N, H, nq, total,
