@@ -326,7 +326,7 @@ int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_
     return FA2_OK;
 }
 
-const char *fa2_version(void) { return "fa2-hip 0.1.0 gfx950"; }
+const char *fa2_version(void) { return "fa2-hip 0.2.0 gfx950"; }
 
 const char *fa2_last_error(void) { return g_err; }
 
