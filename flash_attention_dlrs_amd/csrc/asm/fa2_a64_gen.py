@@ -380,6 +380,8 @@ class Gen:
           I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
           I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
+        if "fire_nocmp" in self.abl:
+            e(I("s_mov_b64", S_FIRE[0], 0), I("s_mov_b64", S_FIRE[1], 0))
         if self.ragged and not self.causal:
             e(comment("ragged, non-causal: real keys in a job's last 256; -inf"),
               I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
@@ -584,6 +586,11 @@ class Gen:
     T_END = 104
     LAZY_TAU = {"ms0": 28, "ms1": 29, "mr": 99, "pm": 100}   # tau of the lazy-masking operations of a diagonal tile (mask_lazy)
 
+    def lazy_tau(self):
+        """(the split row map has no 'ms' / 'mr'; its packed-P masking sits behind the last pack of the plan, which ends two gaps
+        later there: tile_plan, gap2)"""
+        return dict(self.LAZY_TAU, pm=103) if self.split else self.LAZY_TAU
+
     def tile_plan(self, init=False, lean=False):
         """placement of the per-tile softmax operations: returns [(tau, kind, payload)] sorted by tau.
         kinds: 'mx' (g, j)  'dec' (qb, part)  'f' e  'e' e  'cv' (g, j)"""
@@ -635,13 +642,19 @@ class Gen:
             # A job's first tile has no decision to take but keeps the slots: the loop body that finishes it is the one that
             # finishes every other tile, so both placements must agree)
             for part in range(5):
-                t = place(t, (9, 5, 9, 4, 2)[part], "dec", (qb, part)) + 1
+                # (the branch two gaps behind its compare: with one MFMA between them the scalar compare waits ~10 cycles for the
+                # mask -- microbenchmark mb_cmps_a_scmp_brs against mb_cmps_aaa_scmp_brs -- and query block 0's pair sat in the last
+                # gaps in front of the mid-step barrier; now its branch is the first thing behind the barrier)
+                # (not where the lazy masking of the contiguous row map / the ragged key tail pins 'mr' in front of the last packs)
+                gap2 = part == 4 and "fire_adjacent" not in self.abl and (self.split or not (self.causal or self.ragged))
+                t = place(t + (1 if gap2 else 0), (9, 5, 9, 4, 2)[part], "dec", (qb, part)) + 1
             t_dec[qb] = t
         # (causal diagonal tiles handled lazily -- mask_lazy -- add four small operations at LAZY_TAU: gaps of phase A that are
         # nearly empty in every tile, so the plan itself does not reserve anything for them)
         t_d2 = {qb: next(t for t, k, p_ in placed if k == "dec" and p_ == (qb, 2)) for qb in range(2)}
-        lz = self.LAZY_TAU
-        assert lz["mr"] - P < lz["ms0"] < t_d2[0] and lz["mr"] - P < lz["ms1"] < t_d2[1] and lz["pm"] < self.T_END
+        lz = self.lazy_tau()
+        assert self.split or (lz["mr"] - P < lz["ms0"] < t_d2[0] and lz["mr"] - P < lz["ms1"] < t_d2[1])
+        assert lz["pm"] < self.T_END
         # s' = s * c - m, exp2, pack -- element order inside a group is the packing order
         for qb in range(2):
             t_f = t_dec[qb]
@@ -661,7 +674,9 @@ class Gen:
                         tc = place(tc, 5, "cv", (g, j))
                         last_cv.setdefault(g, {})[j] = tc
                     t_e_prev = te
-        assert max(t for t, k, _ in placed if k == "cv") < min(lz["mr"], lz["pm"]), "a pack operation behind the packed-P masking"
+        if self.causal or self.ragged:     # (the kernels that mask lazily)
+            assert max(t for t, k, _ in placed if k == "cv") < (lz["pm"] if self.split else min(lz["mr"], lz["pm"])), \
+                "a pack operation behind the packed-P masking"
         placed.sort(key=lambda x: x[0])
         assert max(t for t, _, _ in placed) < self.T_END, max(t for t, _, _ in placed)
         self._cache[key] = placed
@@ -734,7 +749,11 @@ class Gen:
             if init:
                 return []
             if part == 3:
+                if "fire_nocmp" in self.abl:      # (timing-only: the branch on a stale mask)
+                    return []
                 return [I("v_cmp_gt_f32", S_FIRE[qb], d, S_THR)]
+            if "fire_nobranch" in self.abl:       # (timing-only: the compare without its branch)
+                return []
             l_fire, l_back = self.lab("fire"), self.lab("fire_back")
             # rare: raise this query block's running maximum now (every s' = s * c - m of the PREVIOUS tile has been formed:
             # plan order), remember the factor; O and the row sums are scaled at the end of the coming phase B
@@ -783,7 +802,7 @@ class Gen:
         lazy = (jd, cond) if masks is not None and not init else None
         plan = self.tile_plan(init)
         if lazy is not None:
-            lz = self.LAZY_TAU
+            lz = self.lazy_tau()
             if self.split and not tail:
                 # split row map: a hidden (tile, query block) is not computed at all -- no running-maximum swap ('ms' / 'mr');
                 # the packed-P masking only where this body's waves sit on the tile's diagonal and the block is computed
@@ -1511,7 +1530,8 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
              "nomx": ("no_mx",), "nodec": ("no_dec",), "nofire": ("no_fire",), "nof": ("no_f",), "noe": ("no_e",), "nocv": ("no_cv",),
              "nofecv": ("no_f", "no_e", "no_cv"), "nolds": ("nokread", "novread", "nodma"),
              "nobar_nostart": ("nobarrier", "nostart"), "nobar_nolds": ("nobarrier", "nokread", "novread", "nodma"),
-             "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire")}
+             "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire"),
+             "fire_nocmp": ("fire_nocmp",), "fire_nobranch": ("fire_nobranch",)}
 
 
 # named variants of the experiments build (make experiments; FA2_A64_KERNEL=fa2_fwd_a64_bf16_<c|n>_<tag> selects one per launch:
@@ -1521,7 +1541,7 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
 # lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
 # issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "nosplit_nolean": dict(split=False, abl=("nolean",))}
+VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fireadj": dict(abl=("fire_adjacent",))}
 
 
 def module_text(gens):

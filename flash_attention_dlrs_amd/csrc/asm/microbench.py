@@ -44,6 +44,8 @@ class MB:
         e(I("s_mov_b32", S(21), 1.4426950408889634))
         e(I("s_lshl_b32", S(22), S(20), 12))                 # wave * 4096: LDS-DMA destination
         e(I("s_mov_b32", S(23), 0))
+        e(I("s_mov_b32", S(24), 60.0))
+        e(I("s_mov_b64", S(26, 2), 0)), e(I("s_mov_b64", S(30, 2), 0))
         e(I("s_barrier"))
         e(I("s_memtime", S(12, 2)))
         e(waitcnt(lgkmcnt=0))
@@ -58,6 +60,8 @@ class MB:
             if mfma:
                 e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
             for f in fillers(u):
+                if f.op.startswith("s_cbranch"):      # (the never-taken branch of the fire-test cases: a label of this kernel)
+                    f = I(f.op, Label(f".Lmb_never_{name}"))
                 e(f)
         e(I("s_sub_u32", S(16), S(16), 1))
         e(I("s_cmp_lg_u32", S(16), 0))
@@ -74,6 +78,8 @@ class MB:
         e(I("v_mov_b32", V(205), S(14)))
         e(I("global_store_dword", V(204), V(205), S(4, 2)))
         e(waitcnt(vmcnt=0))
+        e(I("s_endpgm"))
+        e(label(f".Lmb_never_{name}"))
         e(I("s_endpgm"))
 
     # reuse the kernel text / metadata emitters of the a64 generator (same descriptor: 512 registers, static LDS)
@@ -105,8 +111,20 @@ def cases():
     def DMA3(u, k):
         return I("buffer_load_dwordx4", V(201), S(8, 4), 0, offen=1, lds=1)
     M0S = lambda u, k: I("s_add_u32", M0, S(22), 1024 * (u % 4))
+    # the fire test of the softmax plan: a compare into a scalar mask and a branch on it that is never taken (operands are 0.5 / 1.0
+    # against a threshold of 60)
+    THR = lambda: I("s_mov_b32", S(24), 60.0)
+    CMPS = lambda u, k: I("v_cmp_gt_f32", S(26, 2), V(r(u, k)), S(24))
+    CMPV = lambda u, k: I("v_cmp_gt_f32", VCC, V(r(u, k)), S(24))
+    SCMP = lambda u, k: I("s_cmp_lg_u64", S(26, 2), 0)
+    BRS = lambda u, k: I("s_cbranch_scc1", Label(".Lmb_never"))
+    BRV = lambda u, k: I("s_cbranch_vccnz", Label(".Lmb_never"))
+    SOR = lambda u, k: I("s_or_b64", S(28, 2), S(26, 2), S(30, 2))
     pats = {
         "none": [],
+        "aa": [ADD, ADD], "cmps_a": [CMPS, ADD], "cmpv_a": [CMPV, ADD],
+        "cmps_a_scmp_brs": [CMPS, ADD, SCMP, BRS], "cmpv_a_brv": [CMPV, ADD, BRV], "a_scmp_brs": [ADD, SCMP, BRS],
+        "cmps_aaa_scmp_brs": [CMPS, ADD, ADD, ADD, SCMP, BRS], "cmpv_aaa_brv": [CMPV, ADD, ADD, ADD, BRV],
         "t_eafc": [TRR, EXP, ADD, FMA, CVT], "e_t_afc": [EXP, TRR, ADD, FMA, CVT], "eafc_t": [EXP, ADD, FMA, CVT, TRR],
         "t_e": [TRR, EXP], "e_t": [EXP, TRR], "tt_e": [TRR, TRR, EXP], "t_ea": [TRR, EXP, ADD], "t_eaa": [TRR, EXP, ADD, ADD],
         "tt_afc": [TRR, TRR, ADD, FMA, CVT], "t_afcm": [TRR, ADD, FMA, CVT, MX3], "tt_aff": [TRR, TRR, ADD, FMA, FMA],
