@@ -63,6 +63,11 @@ for k, nm in ((10, "phaseA"), (11, "sync"), (12, "phaseB")):
     out[nm + "_cyc_per_step"] = [round(float(lo[:, w, k].double().median()) / steps, 1) for w in range(4)]
 out["seam_steps_cyc"] = [float((d[..., 17] - d[..., 16]).median()), float((d[..., 18] - d[..., 17]).median()),
                          float((d[..., 19] - d[..., 18]).median()), float((d[..., 4] - d[..., 19]).median()), float((d[..., 16] - d[..., 3]).median())]
+# seam steps 2 and 3 of the split causal kernel at their mid-step barrier (slots 22, 23; waves 2, 3 carry them): phase A + barrier | phase B
+if c["causal"]:
+    hi = d[:, 2:, :]
+    out["seam_step2_AB"] = [float((hi[..., 22] - hi[..., 18]).median()), float((hi[..., 19] - hi[..., 22]).median())]
+    out["seam_step3_AB"] = [float((hi[..., 23] - hi[..., 19]).median()), float((hi[..., 4] - hi[..., 23]).median())]
 # inside the epilogue (slot 4 = its start): L + descriptors | block 0 scale/pack/write + read-back issue | block 1 first half |
 # block 0 stores + block 1 second half + read-back issue | O := 0 | block 1 stores
 pts = [d[..., 4], d[..., 13], d[..., 14], d[..., 15], d[..., 20], d[..., 21], d[..., 5]]

@@ -1204,6 +1204,8 @@ class Gen:
         out += self.stamp_acc(0)
         out += self.sync_mid(kw.get("steady", False), kw.get("vm"))
         out += self.stamp_acc(1)
+        if kw.get("mid_stamp") is not None:      # (diagnostic builds: the seam's steps 2 and 3 split at their barrier)
+            out += self.stamp(kw["mid_stamp"])
         out += [comment(f"---- step {t4}: phase B")]
         out += self.phase_b(t4, **kb)
         return out
@@ -1439,7 +1441,7 @@ class Gen:
                             ckw.update(with_qk=False, nxt=False)
                         self.cls = cls
                         if cls == "high":
-                            e(self.step(st, early=early, pre=pre, **ckw), label(l_join))
+                            e(self.step(st, early=early, pre=pre, mid_stamp=20 + st if st >= 2 else None, **ckw), label(l_join))
                         else:
                             body, self.prog = self.prog, []
                             e(label(l_low), self.step(st, early=early, pre=pre, **ckw), I("s_branch", Label(l_join)))
