@@ -105,6 +105,23 @@ def test_emulated_causal_diagonal_with_large_masked_scores(oracle, dtype, thr, s
     assert np.abs(L - L_ref.reshape(L.shape)).max() <= 1.01 * ulp
 
 
+@pytest.mark.parametrize("dtype,thr", [("bf16", None), ("f16", 6.0)])
+def test_split_row_map_is_bit_identical_to_the_contiguous_one(dtype, thr):
+    """the split row map (wave w: 32-row blocks w and w + 4; a hidden (tile, block) pair is not computed) only changes which wave
+    owns a row: every row sees the same tiles in the same order with the same 32-row rescale groups, so O and L must come out
+    bit for bit as with the contiguous map (whose hidden tiles run with +inf as running maximum) -- three jobs per (b, h) incl.
+    a job that is nothing but its diagonal, large masked scores next to the diagonal, and (f16, threshold 6) frequent rescales"""
+    rng = np.random.default_rng(5)
+    B, H, N = 1, 2, 768
+    Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) * 0.6 for _ in range(3))
+    for q, ahead, gain in ((5, 3, 2.0), (100, 60, 8.0), (300, 1, 6.0), (517, 50, 3.0), (600, 100, 5.0)):
+        K[:, :, q + ahead] = gain * Q[:, :, q]
+    kw = dict(thr_override=thr) if thr is not None else {}
+    out = [harness.run(prog(dtype, True, split)[1], Q, K, V, dtype=dtype, causal=True, nwg=1, **kw)[:2] for split in (True, False)]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert not np.isnan(out[0][0]).any()
+
+
 @pytest.mark.parametrize("dtype,causal,N", [("bf16", False, 300), ("bf16", False, 600), ("f16", False, 1000), ("bf16", True, 448), ("f16", True, 520)])
 def test_emulated_ragged_kernels(oracle, dtype, causal, N):
     """N not a multiple of 256: the buffers hold exactly N rows (an unchecked access faults in the emulator), two (b, h) on one
