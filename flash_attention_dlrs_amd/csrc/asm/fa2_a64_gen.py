@@ -237,9 +237,9 @@ class Gen:
                     I("v_mov_b32", V(V_ST_ACC + k), 0)]
         return out
 
-    def udiv(self, q: Reg, r: Reg | None, n: Reg, d: Reg):
+    def udiv(self, q: Reg, r: Reg | None, n: Reg, d: Reg, vt=None):
         """q = n / d, r = n % d for wave-uniform 32-bit values < 2^22 (float reciprocal + one correction each way)"""
-        t0, t1 = V(V_T[0]), V(V_T[1])
+        t0, t1 = vt if vt is not None else (V(V_T[0]), V(V_T[1]))
         st, sr = S_T[6], S_T[7]
         self.e(I("v_cvt_f32_u32", t0, n), I("v_cvt_f32_u32", t1, d), I("s_nop", 0), I("v_rcp_f32", t1, t1), I("s_nop", 1),
                I("v_mul_f32", t0, t0, t1), I("v_cvt_u32_f32", t0, t0), I("s_nop", 1), I("v_readfirstlane_b32", q, t0), I("s_nop", 4),
@@ -401,7 +401,7 @@ class Gen:
                   I("v_or_b32", V(V_PM[j]), t1, t2))
 
     # ------------------------------------------------------------------ job decode: S_JOB (+ S_PASS) -> S_NB, S_NHH, S_NQI, S_NNT
-    def k_decode_next(self):
+    def k_decode_next(self, vt=None):
         e = self.e
         l_else, l_done = self.lab("dec_else"), self.lab("dec_done")
         t = S_T
@@ -427,14 +427,14 @@ class Gen:
           I("s_and_b32", t[0], S_NBH, 7), I("s_cmp_lg_u32", t[0], 0), I("s_cbranch_scc1", Label(l_else)))
         # slot = id >> 3; GN = G * nunit; batch = slot / GN; r = slot % GN; bh = (batch * G + r % G) * 8 + (id & 7); unit = r / G
         e(I("s_lshr_b32", t[0], S_JOB, 3), I("s_mul_i32", t[1], S_G, S_NUNIT))
-        self.udiv(t[2], t[3], t[0], t[1])       # batch, r
-        self.udiv(S_UNIT, t[4], t[3], S_G)      # unit = r / G, r % G
+        self.udiv(t[2], t[3], t[0], t[1], vt)       # batch, r
+        self.udiv(S_UNIT, t[4], t[3], S_G, vt)      # unit = r / G, r % G
         e(I("s_mul_i32", t[2], t[2], S_G), I("s_add_u32", t[2], t[2], t[4]), I("s_lshl_b32", t[2], t[2], 3),
           I("s_and_b32", t[0], S_JOB, 7), I("s_add_u32", bh, t[2], t[0]), I("s_branch", Label(l_done)))
         e(label(l_else))
-        self.udiv(bh, S_UNIT, S_JOB, S_NUNIT)
+        self.udiv(bh, S_UNIT, S_JOB, S_NUNIT, vt)
         e(label(l_done))
-        self.udiv(S_NB, S_NHH, bh, S_H)
+        self.udiv(S_NB, S_NHH, bh, S_H, vt)
         e(label(l_qi))
         if self.causal:
             # unit u, pass 0: qi = nq - 1 - u (heavy), pass 1: qi = u;  tiles = 4 (qi + 1)
@@ -446,9 +446,10 @@ class Gen:
         else:
             e(I("s_mov_b32", S_NQI, S_UNIT), I("s_lshl_b32", S_NNT, S_NQ, 2))      # (4 tiles per 256 rows, N rounded up)
 
-    def k_advance(self):
+    def k_advance(self, vt=None):
         """S_JOB / S_PASS -> the job after the most recently decoded one, decoded into the next-job registers;
-        S_FINAL = 1 if there is none (the next-job registers then repeat the current job)"""
+        S_FINAL = 1 if there is none (the next-job registers then repeat the current job).  vt: two VGPR temporaries for the
+        divisions of the generic decode (default V_T[0], V_T[1])"""
         e = self.e
         l_fin, l_ok = self.lab("adv_final"), self.lab("adv_ok")
         if self.causal:
@@ -462,7 +463,7 @@ class Gen:
         else:
             e(I("s_add_u32", S_JOB, S_JOB, S_NWG))
         e(I("s_cmp_ge_u32", S_JOB, S_TOTAL), I("s_cbranch_scc1", Label(l_fin)), label(l_ok))
-        self.k_decode_next()
+        self.k_decode_next(vt)
         l_done = self.lab("adv_done")
         e(I("s_branch", Label(l_done)), label(l_fin),
           comment("no further job: the seam streams the current job's first tiles again (results discarded)"),
@@ -1269,13 +1270,14 @@ class Gen:
                     out += extras[j]
             return out
 
-        def row_stores(qb):
-            """[[instructions of one row store]] of query block qb (its rows are back in `rows`)"""
-            pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, S_T[0])
-            out = [[I("s_mul_i32", S_T[0], S_QROW[qb], S_OSN), I("s_lshl_b32", S_T[1], S_OSN, 2)] + pre + [st]]
+        def row_stores(qb, off=S_T[0], stride=S_T[1], restride=False):
+            """[[instructions of one row store]] of query block qb (its rows are back in `rows`).  restride: the 4-row stride is
+            formed again in front of every store (scalar code that uses `stride` runs between the stores)"""
+            pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, off)
+            out = [[I("s_mul_i32", off, S_QROW[qb], S_OSN), I("s_lshl_b32", stride, S_OSN, 2)] + pre + [st]]
             for k in range(1, 8):
-                pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, S_T[0])
-                out.append([I("s_add_u32", S_T[0], S_T[0], S_T[1])] + pre + [st])
+                pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, off)
+                out.append(([I("s_lshl_b32", stride, S_OSN, 2)] if restride else []) + [I("s_add_u32", off, off, stride)] + pre + [st])
             return out
 
         def read_back():
@@ -1320,21 +1322,32 @@ class Gen:
         # (the wave can issue one of these every 32 cycles and one row store every ~75 with all four waves storing: interleaved,
         # the stores hide the MFMAs; two MFMAs go first, under the read-back's LDS round trip)
         zero = [I(self.mfma, A_O(qb, db), z, z, 0) for qb in range(2) for db in range(4)]
-        st1 = row_stores(1)
+        # (offset / stride registers the job bookkeeping below leaves alone: k_promote and k_advance use S_T[0..4], [6], [7])
+        st1 = row_stores(1, off=S_T[5], stride=S_T[6], restride=True)
         e(zero[0], zero[1])
         e(self.stamp_async(4))
         e(waitcnt(lgkmcnt=0))
-        for k in range(8):
-            e(st1[k])
-            if k + 2 < 8:
-                e(zero[k + 2])
-        e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the descriptor arithmetic below: it uses the stamp registers)
-        # L store (lanes 0..31), in the I/O dtype: behind the row stores (they hold the vector-memory path for a while)
+        e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the scalar code below: it uses the stamp registers)
+        # L store (lanes 0..31), in the I/O dtype: in front of the job bookkeeping (it needs this job's row numbers and S_T)
         e(I("s_lshr_b64", EXEC, EXEC, 32))
         for qb in range(2):
             pre, st = self.buf_op("buffer_store_short", m2[qb], V(V_L2), S_NVRS, S_T[0])
             e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), pre, st)
         e(I("s_mov_b64", EXEC, -1))
+        for k in range(8):
+            e(st1[k])
+            if k + 2 < 8:
+                e(zero[k + 2])
+            if k == 1:
+                # Job bookkeeping in the shadow of the row stores (the vector-memory path takes ~75 cycles per store with four
+                # waves storing: the scalar code runs while the first two drain): the next job becomes the current one and the
+                # job after it is decoded -- ~200 cycles that used to stand in front of the seam.  S_FINAL still says "this
+                # job is the workgroup's last" for the branch behind the epilogue: it is put aside in S_FLAG (idle between steps)
+                l_last = self.lab("epi_last")
+                e(I("s_mov_b32", S_FLAG, S_FINAL), I("s_cmp_lg_u32", S_FINAL, 0), I("s_cbranch_scc1", Label(l_last)))
+                self.k_promote()
+                self.k_advance(vt=(tset[0][4], tset[0][5]))     # (not z: SBUF[1] + 32..35 is the zero MFMAs' operand)
+                e(label(l_last))
         self.atmp_regs = (V_T[8], V_T[9])
 
     # ------------------------------------------------------------------ the whole kernel
@@ -1347,6 +1360,7 @@ class Gen:
         # ---- first job of this workgroup: decode, descriptors, first loads, pipeline fill
         self.k_decode_next()
         self.k_promote()
+        self.k_advance()      # (every later job is decoded in its predecessor's epilogue, under the row stores)
         e(comment("first job: K / V descriptors, K(0..2), V(0..1) by LDS-DMA, Q rows"))
         e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH, S_KSN), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH, S_VSN))
         e(I("s_mov_b32", S_KDMA, S_KW), I("s_mov_b32", S_VDMA, S_VW))
@@ -1377,7 +1391,6 @@ class Gen:
         e(label(l_seam))
         e(self.stamp(3), self.stamp_acc(2), self.stamp_flush(), self.stamp_job(0))
         # ---- the job's last four tiles: the next job's K / V / Q stream in, its first QK^T and softmax start run here
-        self.k_advance()
         cm = self.causal
         if True:
             kpre = self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_NB, S_NHH, S_KSN) + [I("s_mov_b32", S_KDMA, S_KW)] + \
@@ -1486,8 +1499,8 @@ class Gen:
         e(self.stamp(4), self.stamp_job(1))
         self.k_epilogue()
         e(self.stamp(5))
-        e(I("s_cmp_lg_u32", S_FINAL, 0), I("s_cbranch_scc1", Label(l_end)))
-        self.k_promote()
+        # (S_FLAG: S_FINAL as it stood in front of the epilogue's job bookkeeping; back to 0 for the next step's rescale flag)
+        e(I("s_cmp_lg_u32", S_FLAG, 0), I("s_mov_b32", S_FLAG, 0), I("s_cbranch_scc1", Label(l_end)))
         e(self.stamp(0), self.stamp_acc(3), self.stamp_job(2))
         e(I("s_branch", Label(l_job)))
         e(label(l_end), self.stamp_job(2), self.stamp_job_flush(), waitcnt(vmcnt=0), self.stamp(7, real=True), self.stamp(9), I("s_endpgm"))
