@@ -63,6 +63,13 @@ for k, nm in ((10, "phaseA"), (11, "sync"), (12, "phaseB")):
     out[nm + "_cyc_per_step"] = [round(float(lo[:, w, k].double().median()) / steps, 1) for w in range(4)]
 out["seam_steps_cyc"] = [float((d[..., 17] - d[..., 16]).median()), float((d[..., 18] - d[..., 17]).median()),
                          float((d[..., 19] - d[..., 18]).median()), float((d[..., 4] - d[..., 19]).median()), float((d[..., 16] - d[..., 3]).median())]
+# the same per wave class of the split causal kernel (waves 0-1 take the "low" bodies, waves 2-3 the "high" ones): a wave that is
+# through a step early waits at the next step's barrier, so the class with the LONGER steps is the critical one
+if c["causal"]:
+    for nm, sl in (("low", slice(0, 2)), ("high", slice(2, 4))):
+        w = d[:, sl, :]
+        out["seam_steps_" + nm] = [float((w[..., 17] - w[..., 16]).median()), float((w[..., 18] - w[..., 17]).median()),
+                                   float((w[..., 19] - w[..., 18]).median()), float((w[..., 4] - w[..., 19]).median())]
 # seam steps 2 and 3 of the split causal kernel at their mid-step barrier (slots 22, 23; waves 2, 3 carry them): phase A + barrier | phase B
 if c["causal"]:
     hi = d[:, 2:, :]

@@ -1420,7 +1420,7 @@ class Gen:
                     early += kpre
                 if st == sv:
                     pre += vpre
-                if st == 2:
+                if st == 2 and "noqreads" not in self.abl:   # (timing-only ablation: what the AGPR-destination reads cost)
                     early += self.q_reads()      # slice -> a[128:191] (Q was last read by this step's phase A)
                 if st == 3:
                     early += self.epilogue_descs()
@@ -1590,6 +1590,9 @@ def main(argv=None):
         g.build()
         gens.append(g)
         g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_nosplit", stamps=True, abl=("lite",), split=False)
+        g.build()
+        gens.append(g)
+        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_noqreads", stamps=True, abl=("lite", "noqreads"))
         g.build()
         gens.append(g)
         for nm, abl in [("lite", ())] + list(ABLATIONS.items()):

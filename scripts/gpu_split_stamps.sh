@@ -11,5 +11,5 @@ import sys, json
 for l in sys.stdin:
     if not l.startswith('{'): print(l.strip()); continue
     j = json.loads(l)
-    print(j['kernel'][16:], j['ms'], j['tflops'], 'st2 A|B', j.get('seam_step2_AB'), 'st3 A|B', j.get('seam_step3_AB'), 'seam', j['seam_steps_cyc'], 'epi', j['epilogue_cyc_median'], 'clk', j['clock_ghz'], 'kern', j['kernel_cyc_median'], 'all', j.get('all_jobs_cyc'))
+    print(j['kernel'][16:], j['ms'], j['tflops'], 'low', j.get('seam_steps_low'), 'high', j.get('seam_steps_high'), 'st2 A|B', j.get('seam_step2_AB'), 'st3 A|B', j.get('seam_step3_AB'), 'seam', j['seam_steps_cyc'], 'epi', j['epilogue_cyc_median'], 'clk', j['clock_ghz'], 'kern', j['kernel_cyc_median'], 'all', j.get('all_jobs_cyc'))
 "
