@@ -10,7 +10,7 @@ from .fa2_a64_gen import KARG_SIZE, Gen
 
 LOG2E = 1.4426950408889634
 # deferral threshold of the running maximum (log2 units) the launcher passes (fa2_a64.hip): P <= 2^thr; f16 P must stay below 65 504
-A64_THR = {"bf16": 60.0, "f16": 15.5}
+A64_THR = {"bf16": 60.0, "f16": 15.875}
 
 
 def to_dt(x, dtype):

@@ -93,7 +93,7 @@ def test_many_jobs_per_workgroup_and_job_order(oracle):
 
 
 def test_many_jobs_f16_rescale_across_job_seams():
-    """f16 defers the running maximum by at most 15.5 log2 units, so O and l are rescaled often: with several jobs per workgroup
+    """f16 defers the running maximum by at most 15.875 log2 units, so O and l are rescaled often: with several jobs per workgroup
     every rare path (firing, deferred rescale, epilogue, next job's prefetch) meets every other"""
     dtype = torch.float16
     Q, K, V = rand3((2, 160, 512, 128), dtype, seed=13)      # 640 jobs on 256 workgroups
@@ -122,7 +122,7 @@ def test_strided_inputs(oracle):
 @pytest.mark.parametrize("causal", [False, True])
 def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype, causal):
     """the kernel's liberties are exactly the ones oracle.forward_deferred states (running maximum kept per 32-row query block
-    while no row of it exceeds m by 60 / 15.5 log2 units, exp2(fma), row sums of the rounded P): against THAT restatement the
+    while no row of it exceeds m by 60 / 15.875 log2 units, exp2(fma), row sums of the rounded P): against THAT restatement the
     result is compared element by element -- at least 99 % of O bit-identical; an element that differs is off by its own
     rounding step plus at most one rounding step of P times max |V| (a P that v_exp_f32's last bit rounds the other way moves O
     by its share p / l of V -- early causal rows have few keys and large shares).  What remains besides is the fp32 summation
@@ -133,7 +133,7 @@ def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype,
     O, L = a64(Q, K, V, causal)
     f = lambda t: t.float().numpy()
     O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
-                                           thr=60.0 if dtype == torch.bfloat16 else 15.5, sum_rounded=True)
+                                           thr=60.0 if dtype == torch.bfloat16 else 15.875, sum_rounded=True)
     O, O_ref = O.float(), torch.from_numpy(O_ref)
     same = (O == O_ref).float().mean().item()
     assert same >= 0.99, same
@@ -147,7 +147,7 @@ def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype,
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_rescale_branch_is_exercised(oracle, dtype):
-    """the running maximum of one row jumps far beyond the deferral threshold (60 / 15.5 log2 units) in the last tiles, after O
+    """the running maximum of one row jumps far beyond the deferral threshold (60 / 15.875 log2 units) in the last tiles, after O
     and l are non-zero: O *= coeff, l *= coeff are taken (cdna_hip_programming.md rule 26)"""
     B, H, N = 1, 2, 1024
     Q, K, V = rand3((B, H, N, 128), torch.float32, seed=33, spread=0.3)
@@ -251,7 +251,7 @@ def test_ragged_N_vs_oracle(oracle, dtype, causal):
         assert (arena_o[:, :, N:].float() == 768.0).all() and (arena_l[:, :, N:].float() == 768.0).all(), N
         f = lambda t: t.float().numpy()
         O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
-                                               thr=60.0 if dtype == torch.bfloat16 else 15.5, sum_rounded=True)
+                                               thr=60.0 if dtype == torch.bfloat16 else 15.875, sum_rounded=True)
         O_ref, L_ref = torch.from_numpy(O_ref), torch.from_numpy(L_ref)
         assert (O.cpu().float() == O_ref).float().mean() >= 0.99, N
         check(O.cpu(), L.cpu(), O_ref, L_ref, dtype)

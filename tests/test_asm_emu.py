@@ -50,7 +50,7 @@ def test_generated_module_assembles_for_gfx950(tmp_path):
 def _run(oracle, dtype, causal, B, H, N, scale=1.0, seed=0, spike=False, **kw):
     rng = np.random.default_rng(seed)
     Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) for _ in range(3))
-    if spike:   # a late jump of one row's maximum far beyond the deferred-rescale threshold (60 / 15.5 log2 units)
+    if spike:   # a late jump of one row's maximum far beyond the deferred-rescale threshold (60 / 15.875 log2 units)
         K[:, :, N - 40] = 8.0 * Q[:, :, 5]
     _, p = prog(dtype, causal)
     O, L, _ = harness.run(p, Q, K, V, dtype=dtype, causal=causal, scale=scale, **kw)
