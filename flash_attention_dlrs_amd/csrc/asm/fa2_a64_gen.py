@@ -380,8 +380,6 @@ class Gen:
           I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
           I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
-        if "fire_nocmp" in self.abl:
-            e(I("s_mov_b64", S_FIRE[0], 0), I("s_mov_b64", S_FIRE[1], 0))
         if self.ragged and not self.causal:
             e(comment("ragged, non-causal: real keys in a job's last 256; -inf"),
               I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
@@ -750,8 +748,6 @@ class Gen:
             if init:
                 return []
             if part == 3:
-                if "fire_nocmp" in self.abl:      # (timing-only: the branch on a stale mask)
-                    return []
                 return [I("v_cmp_gt_f32", S_FIRE[qb], d, S_THR)]
             if "fire_nobranch" in self.abl:       # (timing-only: the compare without its branch)
                 return []
@@ -1546,7 +1542,7 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
              "nofecv": ("no_f", "no_e", "no_cv"), "nolds": ("nokread", "novread", "nodma"),
              "nobar_nostart": ("nobarrier", "nostart"), "nobar_nolds": ("nobarrier", "nokread", "novread", "nodma"),
              "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire"),
-             "fire_nocmp": ("fire_nocmp",), "fire_nobranch": ("fire_nobranch",)}
+             "fire_nobranch": ("fire_nobranch",)}
 
 
 # named variants of the experiments build (make experiments; FA2_A64_KERNEL=fa2_fwd_a64_bf16_<c|n>_<tag> selects one per launch:
