@@ -737,14 +737,20 @@ class Gen:
             qb, part = payload
             a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
             d = V(V_T[qb])
+            # A row's 64 scores of a tile sit in two lanes (h = 0, 1).  Whether the running maximum must move is decided on the
+            # lanes' PARTIAL maxima: some lane exceeds the threshold exactly when the row's maximum does -- so the exchange with
+            # lane ^ 32 (move, swap, max: three operations per query block and tile) happens only where the complete maximum is
+            # used: in a job's first tile (it sets m) and at the head of the rare firing path.  "full_max": the exchange in
+            # every tile, as until the end of round 2 (A/B variant)
+            full = init or "full_max" in self.abl
             if part == 0:
-                return [I("v_max_f32", a, a, b), I("v_mov_b32", b, a)]
+                return [I("v_max_f32", a, a, b)] + ([I("v_mov_b32", b, a)] if full else [])
             if part == 1:
-                return [I("v_permlane32_swap_b32", a, b)]
+                return [I("v_permlane32_swap_b32", a, b)] if full else []
             if part == 2:
                 if init:
                     return [I("v_max_f32", a, a, b), I("v_mul_f32", V(V_MC[qb]), S_C, a)]
-                return [I("v_max_f32", a, a, b), I("v_fma_f32", d, a, S_C, -V(V_MC[qb]))]
+                return ([I("v_max_f32", a, a, b)] if full else []) + [I("v_fma_f32", d, a, S_C, -V(V_MC[qb]))]
             if init:
                 return []
             if part == 3:
@@ -756,7 +762,8 @@ class Gen:
             # plan order), remember the factor; O and the row sums are scaled at the end of the coming phase B
             t2, t3 = V(V_T[2 + 2 * qb]), V(V_T[3 + 2 * qb])
             exact = self.fire_exact(Sb, qb, lazy) if lazy is not None else []
-            self.ool.append([label(l_fire)] + exact + [I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
+            swap = [] if "full_max" in self.abl else [I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b)]
+            self.ool.append([label(l_fire)] + exact + swap + [I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
                              I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
                              I("s_or_b32", S_FLAG, S_FLAG, 1 << qb), I("s_branch", Label(l_back))])
             return [I("s_cmp_lg_u64", S_FIRE[qb], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
@@ -1552,7 +1559,7 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
 # lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
 # issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fireadj": dict(abl=("fire_adjacent",))}
+VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",))}
 
 
 def module_text(gens):
