@@ -1094,7 +1094,7 @@ class Gen:
             for qb in range(2):
                 pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
                 out.append(I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}")
-                           if qb in qbs else None)
+                           if qb in qbs and "no_rowsum" not in self.abl else None)   # (no_rowsum: timing-only, l stays 0)
         return out
 
     def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
@@ -1559,7 +1559,8 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
 # lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
 # issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",))}
+VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)),
+            "norowsum": dict(abl=("no_rowsum",))}     # (norowsum: timing-only bound of what the row-sum MFMAs cost; outputs are wrong)
 
 
 def module_text(gens):

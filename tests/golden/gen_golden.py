@@ -136,5 +136,22 @@ def main():
          O_sdpa=sdpa64(Q.float(), K.float(), V.float()).float().numpy())
 
 
+def main_d128():
+    """(8) round 3: the head size of the north-star kernel.  The default f16/bf16 kernel `a64` needs d = 128 and N >= 256, and
+    fp32 at d = 128 is the reference test's own head size (src/test_correctness.py:9-14) -- no vector above covers either.
+    Run separately (`python tests/golden/gen_golden.py d128`) so the fixtures above are not rewritten."""
+    Q, K, V = randn((1, 1, 512, 128), 15, torch.float16)     # two 256-row jobs of the a64 kernel, eight 64-key tiles
+    O, L = run_ref_kernel(Q, K, V, 64, 64)
+    save("d128_f16_n512_seed15", Q=bits(Q), K=bits(K), V=bits(V), O_ref_64x64=bits(O), L_ref_64x64=bits(L),
+         O_sdpa=sdpa64(Q, K, V).float().numpy())
+    Q, K, V = randn((1, 1, 256, 128), 16)
+    O, L = run_ref_kernel(Q, K, V, 32, 32)
+    save("d128_f32_n256_seed16", Q=bits(Q), K=bits(K), V=bits(V), O_ref_32x32=bits(O), L_ref_32x32=bits(L),
+         O_sdpa=sdpa64(Q, K, V).float().numpy())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "d128":
+        main_d128()
+    else:
+        main()

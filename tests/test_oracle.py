@@ -55,6 +55,24 @@ def test_fp16_matches_reference_kernel(oracle):
     assert np.abs(O - g["O_sdpa"]).max() < 4e-3
 
 
+def test_d128_vectors_of_the_reference_kernel(oracle):
+    """round 3: the reference kernel's own outputs at the head size of the default 16-bit kernel (fp16, N = 512: two 256-row
+    jobs of eight 64-key tiles) and of the reference test (fp32, d = 128) -- tests/golden/gen_golden.py d128"""
+    g = load_golden("d128_f16_n512_seed15")
+    Q, K, V = (g[k].astype(np.float32) for k in "QKV")
+    O, L = oracle.forward(Q, K, V, "float16", B_r=64, B_c=64)
+    O_ref, L_ref = g["O_ref_64x64"].astype(np.float32), g["L_ref_64x64"].astype(np.float32)
+    assert (O == O_ref).mean() > 0.97
+    assert np.abs(O - O_ref).max() <= 2 ** -8           # <= 1 fp16 ulp at |O| < 4 (scores at d = 128: near-one-hot rows, |O| up to ~4)
+    assert (L == L_ref).mean() > 0.97 and np.abs(L - L_ref).max() <= 0.125   # 1 fp16 ulp at |L| in [128, 256)
+    assert np.abs(O - g["O_sdpa"]).max() < 6e-3
+    g = load_golden("d128_f32_n256_seed16")
+    O, L = oracle.forward(g["Q"], g["K"], g["V"], "float32", B_r=32, B_c=32)
+    assert np.abs(O - g["O_ref_32x32"]).max() < 2e-5
+    assert np.abs(L - g["L_ref_32x32"]).max() < 1e-4
+    assert close(O, g["O_sdpa"]) and np.abs(O - g["O_sdpa"]).max() < 1e-3
+
+
 def _interp_quirk_e5m2(x):
     """fp32 -> e5m2 as Triton 3.6's CPU interpreter does it for `.to(float8e5, "rtne")`
     (triton/runtime/interpreter.py _convert_float): truncate the mantissa, add the cut-off bit, and
