@@ -161,7 +161,8 @@ def measured_peak(dtype):
 
 
 # BASELINE.json configs[3] / configs[4]: the whole problem, sharded over the heads (c4) or over batch x heads (c5)
-STRONG = {4: dict(name="c4", B=8, H=32, N=8192, d=128, dtype="bf16", causal=False),
+STRONG = {2: dict(name="c4", B=8, H=32, N=8192, d=128, dtype="bf16", causal=False),
+          4: dict(name="c4", B=8, H=32, N=8192, d=128, dtype="bf16", causal=False),
           8: dict(name="c5", B=16, H=64, N=16384, d=128, dtype="fp8", causal=False)}
 
 
@@ -210,6 +211,39 @@ def strong_scaling(c, world, rank, dev, sync_all, iters=5):
             "tflops_aggregate_with_gather": round(F / t_gather / 1e12, 1)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: this process starts N fresh rank processes (one per GPU) through
+    `python -m torch.distributed.run` as a CHILD, relays rank 0's JSON line and returns the children's worst exit code.  It runs
+    before anything here touches the GPU: the parent never initialises HIP and never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = 0
+    for line in proc.stdout:
+        try:
+            is_result = "metric" in json.loads(line)
+        except ValueError:
+            is_result = False
+        if is_result and lines == 0:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write(f"bench.py: the rank processes printed {lines} result lines\n")
+        return 1
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,7 +254,12 @@ def main():
     ap.add_argument("--gather", action="store_true", help="include the RCCL all-gather of O in the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the scaled-input and gather side measurements")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the rank processes from this process even for --gpus 1 (what --gpus N > 1 does when not under torch.distributed.run)")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and (args.gpus > 1 or args.self_launch):
+        sys.exit(self_launch(args.gpus))
 
     import torch.distributed as dist
     from flash_attention_dlrs_amd import _lib, flash_attention_forward
@@ -230,8 +269,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but torch.distributed.run started {world} ranks")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torch.distributed.run, also at world size 1
@@ -394,6 +432,7 @@ def main():
                          "measured_mfma_only_peak": measured_peak(c["dtype"])},
             "cpu_baseline": cpu,
             "extras": extras,
+            "n_ranks_seen_by_rccl": dist.get_world_size() if grouped else None,
             "lib": _lib.version(),
         }
         print(json.dumps(out))

@@ -74,6 +74,28 @@ class PW:
         # the multiset as 16 half-gap groups (one per 16x16x32 MFMA; two consecutive ones per 32x32x16 MFMA)
         if fill is None:
             groups = [[] for _ in range(16)]
+        elif fill in ("split", "split_nolds", "nomax"):
+            # exp alone in the even half-gaps; fma + (max3 | cvt) in the odd ones; LDS reads lead the odd ones
+            groups = []
+            for v in range(16):
+                g = []
+                if v % 2 == 0:
+                    g.append(EXP(3 * v))
+                    if v in (6, 14):
+                        g.append(SAL(v))
+                else:
+                    if fill == "split":
+                        if v % 4 == 1:
+                            g.append(TRR(v))
+                        if v in (3, 11):
+                            g.append(DSR(v))
+                    g.append(FMA(3 * v))
+                    if v % 4 == 1:
+                        if fill != "nomax":
+                            g.append(MX3(5 * v))
+                    else:
+                        g.append(CVT(5 * v))
+                groups.append([x for x in g if x is not None])
         else:
             groups = []
             for v in range(16):
@@ -143,6 +165,9 @@ def cases():
         out.append(PW(f"pw_{shape}_full", shape, "full"))
         out.append(PW(f"pw_{shape}_noexp", shape, "noexp"))
         out.append(PW(f"pw_{shape}_valu", shape, "full", lds=False))
+        out.append(PW(f"pw_{shape}_split", shape, "split"))
+        out.append(PW(f"pw_{shape}_splitv", shape, "split_nolds"))
+        out.append(PW(f"pw_{shape}_nomax", shape, "nomax"))
     return out
 
 

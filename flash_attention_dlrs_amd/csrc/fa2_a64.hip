@@ -58,7 +58,13 @@ DevState *dev_state() {
         fa2_set_error("a64: code object could not be loaded on device %d", dev);
         return nullptr;
     }
+    // The first launch on a device loads the code object.  That launch may sit inside a stream capture (a caller building a
+    // HIP graph without a warm-up call): loading a module is not a stream operation, but under the default (global) capture
+    // mode the runtime refuses "unsafe" calls from a capturing thread -- so this thread is relaxed for the duration of the load.
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
     hipError_t e = hipModuleLoadData(&d.mod, (const void *)fa2_a64_hsaco_start);
+    if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
     if (e != hipSuccess) {
         d.failed = true;
         fa2_set_error("a64: hipModuleLoadData failed: %s", hipGetErrorString(e));

@@ -57,6 +57,10 @@ int validate(const Fa2Problem &p) {
 // The static tile table, keyed like the reference's autotuner on (B, H, N, d) (plus dtype, causal, strides): the grid
 // size B * H * tiles decides between the key-split, 4-wave and one-workgroup-per-CU kernels.
 int pick_variant(const Fa2Problem &p) {
+    // The thresholds below were measured on the full chip (256 CUs) and are written in tiles / jobs per 256 CUs: T(n) scales
+    // them to the CU count of the current device (a partitioned or smaller part fills at proportionally smaller grids).
+    const int cus = fa2_device_cus();
+    auto T = [cus](long long n) { return (n * cus + 128) / 256; };
     if (fa2_mfma16_supports(p)) {
         // Software-pipelined kernel with LDS-DMA staging.  8 waves x 32 rows halves the K/V traffic per query
         // row; it needs enough 256-row tiles to fill 256 CUs, otherwise the 128-row tile spreads the work wider.
@@ -64,7 +68,7 @@ int pick_variant(const Fa2Problem &p) {
         const bool fits32 = (int64_t)(p.N + 512) * p.ks[2] * 2 < (1LL << 31) && (int64_t)(p.N + 512) * p.vs[2] * 2 < (1LL << 31) &&
                             (int64_t)(p.N + 512) * p.os[2] * 2 < (1LL << 31);
         const long long wg256 = (long long)((p.N + 255) / 256) * p.B * p.H;
-        if (!fits32) return wg256 >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
+        if (!fits32) return wg256 >= T(512) ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
         // d = 128, N a multiple of 256: the generated assembly kernel A64 (4 waves x 64 rows, one wave per SIMD, O / Q / V^T in
         // the accumulator file) wins from 64 jobs of 256 rows on -- a quarter of the CUs busy -- non-causal, and causal from
         // 192 jobs (or 96 when a job has at least eight key tiles); below that the key-split kernels keep more CUs busy.
@@ -72,15 +76,15 @@ int pick_variant(const Fa2Problem &p) {
         // MFMA16D_W4 / MFMA16H / MFMA16K it is 4-33 % faster on every shape from those sizes up (the persistent grid also
         // takes job counts that are not a multiple of the CU count better: 1.5 jobs per CU 180 vs 213 us); on the same
         // MI355X against MFMA16H: c3 causal +15-19 %, c3 shape non-causal +15-17 %.
-        if (fa2_a64_supports(p) && (p.causal ? (wg256 >= 192 || (wg256 >= 96 && p.N >= 2048)) : wg256 >= 64)) return FA2_VARIANT_A64;
+        if (fa2_a64_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) return FA2_VARIANT_A64;
         // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and
         // every workgroup walks its key tiles in sequence -- latency-bound.  MFMA16K splits the keys of a tile among
         // wave groups of the same workgroup (no workspace): benchmarks/tiny_grid.py, HIP-graph replay, fp16:
         // B2 H8 N1024 d64 (BASELINE.json configs[1]) 16.8 -> 11.2 us; d = 128 25.3 -> 21.2; causal d = 128 38.6 -> 21.2;
         // B1 H8 N4096 d128 causal 112.8 -> 79.3.  At 192 units and above the plain kernels are as fast or faster.
         const long long wg128 = (long long)((p.N + 127) / 128) * p.B * p.H;
-        if ((p.causal ? wg128 / 2 : wg128) <= 128) {
-            if (wg128 > 128) return FA2_VARIANT_MFMA16K;  // causal, 129..256 tiles: 128-row tiles, two key groups
+        if ((p.causal ? wg128 / 2 : wg128) <= T(128)) {
+            if (wg128 > T(128)) return FA2_VARIANT_MFMA16K;  // causal, 129..256 tiles: 128-row tiles, two key groups
             if (p.d == 64 && p.N >= 512) return FA2_VARIANT_MFMA16K_R2K4;
             return FA2_VARIANT_MFMA16K_R2K2;
         }
@@ -93,15 +97,15 @@ int pick_variant(const Fa2Problem &p) {
         // -20 %, 256 tiles: MFMA16D_W4 -25 %.
         const int nq256 = (p.N + 255) / 256;
         const long long jobs = (long long)(p.causal ? (nq256 + 1) / 2 : nq256) * p.B * p.H;  // of MFMA16H
-        const double x = (double)jobs / 256.0;
-        const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + 255) / 256) / x <= 1.2;  // <= 20 % lost to whole jobs
+        const double x = (double)jobs / (double)cus;
+        const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + cus - 1) / cus) / x <= 1.2;  // <= 20 % lost to whole jobs
         // (two full rounds of the 8-wave key-split workgroups: B1 H16 N4096 98 vs 105 us, B1 H8 N8192 173 vs 191; at
         // 1.5 rounds -- 384 tiles -- it loses 50 %)
-        if (p.causal && p.d == 128 && wg128 > 448 && wg128 <= 512 && p.N >= 4096) return FA2_VARIANT_MFMA16K;
+        if (p.causal && p.d == 128 && wg128 > T(448) && wg128 <= T(512) && p.N >= 4096) return FA2_VARIANT_MFMA16K;
         if (p.d == 128) {
-            if (p.causal ? wg256 < 320 : (wg256 < 160 || !even)) return FA2_VARIANT_MFMA16D_W4;
+            if (p.causal ? wg256 < T(320) : (wg256 < T(160) || !even)) return FA2_VARIANT_MFMA16D_W4;
         } else {
-            if (wg256 < 160 || !even) return FA2_VARIANT_MFMA16D_W4;
+            if (wg256 < T(160) || !even) return FA2_VARIANT_MFMA16D_W4;
         }
         // 8-wave tiles: MFMA16H (persistent grid, next-job prefetch, hand-ordered steady loop).  Against MFMA16D on
         // MI355X (benchmarks/lottery.py, alternating order): non-causal +4.4 % (d = 128, N = 4096), +3.4 % (N = 8192),
@@ -118,15 +122,15 @@ int pick_variant(const Fa2Problem &p) {
         const int nq256 = (p.N + 255) / 256;
         const long long wg256 = (long long)nq256 * p.B * p.H;
         const long long jobs = (long long)(p.causal ? (nq256 + 1) / 2 : nq256) * p.B * p.H;
-        const double x = (double)jobs / 256.0;
-        const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + 255) / 256) / x <= 1.2;
-        return wg256 >= 160 && even ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
+        const double x = (double)jobs / (double)cus;
+        const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + cus - 1) / cus) / x <= 1.2;
+        return wg256 >= T(160) && even ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
     }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;
     // 16-bit head sizes other than 64 / 128 (multiples of 8): the first MFMA kernel with the missing columns zero-filled
     // on load; 8 waves when there are enough 256-row tiles for the 256 CUs
     if (fa2_mfma16_supports_dp(p))
-        return (long long)((p.N + 255) / 256) * p.B * p.H >= 512 ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
+        return (long long)((p.N + 255) / 256) * p.B * p.H >= T(512) ? FA2_VARIANT_MFMA16_W8 : FA2_VARIANT_MFMA16;
     return FA2_VARIANT_GENERIC;
 }
 

@@ -55,12 +55,13 @@ int main(int argc, char** argv) {
         ms /= 50;
         std::vector<unsigned> h(8192);
         hipMemcpy(h.data(), out, (size_t)cus * 4 * 8, hipMemcpyDeviceToHost);
-        std::vector<double> cyc, ghz;
-        for (int w = 0; w < cus * 4; ++w) { cyc.push_back(h[2 * w]); ghz.push_back(h[2 * w] / (h[2 * w + 1] * 10.0) ); }
-        std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
+        std::vector<double> cyc, ghz, us;
+        for (int w = 0; w < cus * 4; ++w) { cyc.push_back(h[2 * w]); ghz.push_back(h[2 * w] / (h[2 * w + 1] * 10.0)); us.push_back(h[2 * w + 1] * 0.01); }
+        std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end());
         const double tf = unit_flops * args.iters * cus * 4 / (ms * 1e-3) / 1e12;
-        printf("%-14s %7.1f cycles/unit  clock %.3f GHz (min %.3f max %.3f)  %7.1f TFLOP/s  launch %.4f ms\n", name.c_str(),
-               cyc[cyc.size() / 2] / args.iters, ghz[ghz.size() / 2], ghz.front(), ghz.back(), tf, ms);
+        printf("%-16s cycles/unit %6.1f (min %6.1f max %6.1f)  clock %.3f GHz (min %.3f max %.3f)  loop us %6.1f (min %6.1f max %6.1f)  %7.1f TFLOP/s  launch %.4f ms\n",
+               name.c_str(), cyc[cyc.size() / 2] / args.iters, cyc.front() / args.iters, cyc.back() / args.iters, ghz[ghz.size() / 2], ghz.front(),
+               ghz.back(), us[us.size() / 2], us.front(), us.back(), tf, ms);
         fflush(stdout);
     }
     return 0;

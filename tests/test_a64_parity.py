@@ -275,6 +275,37 @@ def test_two_streams_at_once():
     assert torch.equal(Oa, Oa2) and torch.equal(La, La2) and torch.equal(Ob, Ob2) and torch.equal(Lb, Lb2)
 
 
+def test_first_launch_of_the_process_under_stream_capture():
+    """"safe under stream capture" -- for the default kernel too, whose first launch on a device loads its code
+    object (hipModuleLoadData): a fresh process captures variant "a64" into a HIP graph with NO warm-up call, replays it on new
+    contents of the same buffers and compares with an eager launch, bit for bit."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import torch, flash_attention_dlrs_amd as fa
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(11)
+mk = lambda: torch.randn(2, 4, 512, 128, generator=gen).to(torch.bfloat16).to(dev)
+Q, K, V = mk(), mk(), mk()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    O_g, L_g = fa.flash_attention_forward(Q, K, V, dev, causal=True, variant="a64")
+for t in (Q, K, V):
+    t.copy_(mk())
+g.replay()
+torch.cuda.synchronize()
+O_e, L_e = fa.flash_attention_forward(Q, K, V, dev, causal=True, variant="a64")
+torch.cuda.synchronize()
+assert torch.isfinite(O_e.float()).all() and O_e.float().abs().max() > 0.5
+assert torch.equal(O_g, O_e) and torch.equal(L_g, L_e)
+print("CAPTURE_OK")
+"""
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CAPTURE_OK" in out.stdout, out.stderr[-2000:]
+
+
 def test_unsupported_shapes_raise_and_auto_falls_back():
     Q, K, V = rand3((1, 2, 200, 128), torch.bfloat16, seed=1)
     with pytest.raises(TypeError):

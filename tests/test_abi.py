@@ -39,10 +39,12 @@ def test_library_exports_every_declared_symbol():
         assert re.search(rf"\bT {name}\b", out), name
 
 
-def test_exported_fa2_symbols_are_only_the_c_abi():
+def test_exported_symbols_are_only_the_c_abi():
+    """EVERY defined symbol of the dynamic table, whatever its type or mangling (the library links with the version script
+    csrc/fa2_exports.map: C++ launchers, helpers and hipcc's per-unit markers are local)"""
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    exported = set(re.findall(r"\bT (fa2_\w+)\b", out))
-    assert exported == set(declared_functions())
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == set(declared_functions()), sorted(exported ^ set(declared_functions()))
 
 
 def test_header_compiles_as_plain_c(tmp_path):

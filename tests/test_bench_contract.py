@@ -50,6 +50,14 @@ def test_distributed_launcher_world1():
     assert g["included_in_step"] is True and g["world_size"] == 1 and g["ms_compute_plus_gather"] > 0
 
 
+def test_gpus_flag_starts_its_own_rank_processes():
+    """`python bench.py --gpus N` as a plain command (no torch.distributed.run around it): the parent spawns the ranks, relays
+    rank 0's line and exit code.  One GPU here, so the branch is forced with --self-launch at N = 1."""
+    j = _run([sys.executable, "bench.py", "--gpus", "1", "--self-launch", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert j["n_gpus"] == 1 and j["value"] > 0
+    assert j["n_ranks_seen_by_rccl"] == 1        # the rank process ran under torch.distributed.run with the nccl group up
+
+
 def test_query_tile_reports_the_variant_the_launch_takes():
     from flash_attention_dlrs_amd import _lib
     # c2 (B2 H8 N1024 d64 fp16) is a small grid: the key-split kernel, not the large-grid answer

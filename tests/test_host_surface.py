@@ -117,3 +117,18 @@ def test_autotune_key_and_table_roundtrip(tmp_path, monkeypatch):
         autotune.enable(False)
     Q = q(4, 32, 4096, 128)
     assert autotune.pick(Q, Q, Q, Q, Q, _lib.FA2_DTYPE_BF16, True, 1.0) == _lib.VARIANT_AUTO
+
+
+def test_bench_self_launch_relays_the_ranks_exit_code_without_a_gpu():
+    """bench.py --gpus 2 outside torch.distributed.run starts its own rank processes; on a box without GPUs the ranks fail and
+    the parent must hand their failure on (non-zero exit, no result line) instead of crashing or printing a made-up line"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
