@@ -20,9 +20,10 @@ VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA16, VARIANT_MFMA16_W8, VARIANT_MFMA32
     VARIANT_MFMA16K_R2K2 = range(21)
 VARIANT_MFMA16K_R2K4 = 23  # 21 / 22 are the experimental MFMA16P schedules
 VARIANT_A64 = 24
+VARIANT_A16 = 25
 VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_MFMA16,
             "mfma16_w8": VARIANT_MFMA16_W8, "mfma32": VARIANT_MFMA32, "mfma16p": VARIANT_MFMA16P,
-            "mfma16p_w8": VARIANT_MFMA16P_W8, "mfma16x": VARIANT_MFMA16X, "mfma16d": VARIANT_MFMA16D, "mfma16d_w4": VARIANT_MFMA16D_W4, "mfma16h": VARIANT_MFMA16H, "mfma16h_w4": VARIANT_MFMA16H_W4, "mfma16s": VARIANT_MFMA16S, "mfma16s_w4": VARIANT_MFMA16S_W4, "mfma8": VARIANT_MFMA8, "mfma8_w4": VARIANT_MFMA8_W4, "mfma8x": VARIANT_MFMA8X, "mfma8x_w4": VARIANT_MFMA8X_W4, "mfma8u": VARIANT_MFMA8U, "mfma16k": VARIANT_MFMA16K, "mfma16k_r2k2": VARIANT_MFMA16K_R2K2, "mfma16k_r2k4": VARIANT_MFMA16K_R2K4, "a64": VARIANT_A64, "mfma16p_x1": VARIANT_MFMA16P + 16,
+            "mfma16p_w8": VARIANT_MFMA16P_W8, "mfma16x": VARIANT_MFMA16X, "mfma16d": VARIANT_MFMA16D, "mfma16d_w4": VARIANT_MFMA16D_W4, "mfma16h": VARIANT_MFMA16H, "mfma16h_w4": VARIANT_MFMA16H_W4, "mfma16s": VARIANT_MFMA16S, "mfma16s_w4": VARIANT_MFMA16S_W4, "mfma8": VARIANT_MFMA8, "mfma8_w4": VARIANT_MFMA8_W4, "mfma8x": VARIANT_MFMA8X, "mfma8x_w4": VARIANT_MFMA8X_W4, "mfma8u": VARIANT_MFMA8U, "mfma16k": VARIANT_MFMA16K, "mfma16k_r2k2": VARIANT_MFMA16K_R2K2, "mfma16k_r2k4": VARIANT_MFMA16K_R2K4, "a64": VARIANT_A64, "a16": VARIANT_A16, "mfma16p_x1": VARIANT_MFMA16P + 16,
             "mfma16p_w8_x1": VARIANT_MFMA16P_W8 + 16,
             # timing-only ablations, present only in -DFA2_ABLATIONS builds of the library
             "abl_noexp": VARIANT_MFMA16P_W8 + 32, "abl_nosum": VARIANT_MFMA16P_W8 + 64,

@@ -199,7 +199,7 @@ def check(prog, verbose=True):
                     for r in u:
                         if r in last_trans_def and dist(last_trans_def[r]) < 1:
                             errs.append((idx, "R3 trans->valu", r, dist(last_trans_def[r])))
-                if ins.op == "v_permlane32_swap_b32":
+                if ins.op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32"):
                     for r in u:
                         if r in last_valu_def and dist(last_valu_def[r]) < 2:
                             errs.append((idx, "R4 valu->permlane", r, dist(last_valu_def[r])))

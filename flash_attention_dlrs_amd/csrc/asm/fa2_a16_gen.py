@@ -1,31 +1,30 @@
 #!/usr/bin/env python3
-"""Generator of the gfx950 assembly kernels `fa2_fwd_a64_<dtype>_<c|n>` -- FA-2 forward, d = 128, f16 / bf16.
+"""Generator of the gfx950 assembly kernels `fa2_fwd_a16_<dtype>_<c|n>` -- FA-2 forward, d = 128, f16 / bf16: the a64 structure
+(fa2_a64_gen.py: 4 waves x 64 query rows, one wave per SIMD with all 512 registers, persistent grid, continuous tile stream,
+LDS-DMA staging, modulo-scheduled softmax in the MFMA gaps) on the OTHER matrix shape, v_mfma_f32_16x16x32.
 
-Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108 (exp2-domain online softmax in fp32, P rounded
-RTNE to the I/O dtype before P.V, O /= l once at the end, L = m + log2 l), as in fa2_mfma16h.hip.
+Why: under the a64 kernel's filler load the chip holds 1.74-1.81 GHz on the 32x32x16 stream and 2.09-2.20 GHz on the 16x16x32
+stream of the same FLOPs (profiles/r03/powerprobe_mfma_shapes.txt; MI355X_MICROARCH.md 'DVFS give-back' item 7) -- the 16x16 form
+costs 12 % more cycles (an MFMA holds the vector issue port 8 of its 16 cycles) and still finishes 6-8 % earlier.
 
-Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent structure"):
-  * workgroup = 4 waves = one 256-row Q block; a wave owns two 32-row query blocks (qb = 0, 1) and the WHOLE 512-entry
-    register file: O^T in a[0:127], Q in a[128:191], the V^T fragments in a[192:255]; two score buffers, the current
-    K tile and the softmax state in the arch VGPRs;
-  * swapped products: S^T[key][query] = K.Q^T, O^T[d][query] += V^T.P^T on v_mfma_f32_32x32x16 -- a lane owns one query
-    row per query block, P never leaves the registers (the S accumulator, packed in place, is the B operand of P.V);
-  * 64-key K/V tiles arrive by LDS-DMA (buffer_load ... lds) into rings of FOUR K and four V buffers; LDS image = 8-row x
-    32-column subtiles of 512 B with the 16-byte slots XOR-swizzled (T10 image (a)): row reads (ds_read_b128) and
-    transposed reads (ds_read_b64_tr_b16) are conflict-free and need two per-lane base registers each, the rest is an
-    immediate;
-  * per tile t two phases of 32 MFMAs:  A(t) = QK^T(t+1) || finish-softmax(t) (exp2, row sums, cvt) || V(t) tr-reads
-                                        B(t) = P.V(t)    || start-softmax(t+1) (row max, decision, s*c - m) || K(t+2) reads
-                                                         || LDS-DMA of V(t+3), K(t+4)
-    ONE barrier per tile (between A and B) behind a COUNTED `s_waitcnt vmcnt(8)`: a tile's DMA pieces have two tile steps
-    to land.  The loop body is four tiles (buffer indices and score-buffer parity are immediates);
-  * the tile stream is CONTINUOUS across jobs: every job has a multiple of four tiles, and its last body (the "seam")
-    already streams the next job's K(0..3), V(0..2) and Q rows and computes its first QK^T; only the epilogue (O through
-    the wave's LDS slice, L) sits between two jobs;
-  * persistent grid: a workgroup walks its jobs (non-causal: one Q block; causal: the pair (nq-1-u, u)).
+Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108, as fa2_a64_gen.py.
 
-The instruction stream is built as isa.Inst objects: printed to a .s file for the assembler, checked by check.py (wait
-states) and executed by emu.py in the CPU test-suite (tests/test_asm_emu.py) against an fp64 reference.
+What changes against fa2_a64_gen.py is the LAYOUT, not the schedule.  A wave's 64 query rows are four 16-row blocks qb16; a
+64-key tile is four 16-key blocks kb16 = 2 kk + k' (kk: the 32-key half = one k-step of P.V); lane l = 16 g + li.
+  * S^T(kb16, qb16) = K(kb16, ks) . Q(qb16, ks)^T summed over the four 32-column steps ks: A = K rows (lane: key li, columns
+    32 ks + 8 g ..), B = Q rows (lane: query li), D: lane holds query li and keys 16 kb16 + 4 g + r, r = 0..3;
+  * a score GROUP gi = 2 qh + kk (qh = qb16 >> 1: the 32-row "query block" of the a64 plan) is 16 registers: + 8 (qb16 & 1)
+    + 4 k' + r.  Packed in place, registers + 8 (qb16 & 1) .. + 3 are the B operand P^T(qb16, kk) of the second product:
+    k index 8 g + j <-> key 32 kk + 16 (j >> 2) + 4 g + (j & 3) -- no lane exchange, as in a64;
+  * O^T(db16, qb16) += V^T(db16, kk) . P^T(qb16, kk): the V^T fragment of a lane (d = 16 db16 + li) is two transposing LDS reads
+    of four keys each (32 kk + 16 u + 4 g + 0..3);
+  * one MFMA "slot" of the a64 schedule (32 cycles) is a PAIR of 16x16x32 MFMAs that share their A operand (the two 16-row
+    blocks of a query block); the slot's fillers are split between the two.  Slot counts, the softmax plan, the seam and the
+    job stream are a64's;
+  * row sums: v_mfma_f32_16x16x32 with an all-ones A operand -- every row of its D is the 32-key sum of the lane's own query.
+LDS image of a K / V tile: two column halves of 64 rows x 128 bytes, the eight 16-byte chunks of a half row XOR-swizzled by
+(row & 6): conflict-free for the ds_read_b128 row reads of the 16x16x32 A operand and for the transposing reads
+(tests/test_asm_a16.py checks both against the bank model of MI355X_MICROARCH.md).
 """
 from __future__ import annotations
 
@@ -36,56 +35,58 @@ from .isa import A, EXEC, I, Inst, Label, M0, Reg, S, V, VCC, comment, label, wa
 
 # ------------------------------------------------------------------------------------------------- register map
 # arch VGPRs
-SBUF = (0, 64)            # two score buffers of 64 registers: group g = 2*qb + kb at +16 g
-VF = 128                  # V^T fragments: (kstep, db) at VF + 4 * (4 * kstep + db)
-V_KRE, V_KRO = 192, 193   # K row-read lane bases (even / odd k-step)
-V_VR0, V_VR1 = 194, 195   # V transposed-read lane bases (u = 0 / 1), the V ring's LDS offset included
-V_DKO, V_DVO = 196, 197   # LDS-DMA per-lane source offsets (K / V row stride)
-V_MC = (198, 199)         # running row maximum in the exp2 domain (c * max), per query block
-V_RS = ((200, 201), (202, 203))  # (unused: the row sums live in V_LACC)
-V_MX = ((204, 205), (206, 207))  # row-max chains [qb][kb]
-V_CO = (208, 209)         # rescale coefficient per query block
-V_T = tuple(range(210, 220))     # temporaries (V_T[2] = v212 is 4-aligned: a zero MFMA operand in the epilogue)
-V_QOFF = 220              # (unused)
+SBUF = (0, 64)            # two score buffers of 64 registers: group gi = 2 qh + kk at + 16 gi, inside + 8 (qb16 & 1) + 4 (kb16 & 1) + r
+KF = 128                  # K fragments of the next tile: (kb16, ks) at KF + 4 (4 kb16 + ks)
+V_KR = (192, 193)         # K row-read lane bases (even / odd 32-column step)
+V_VR = (194, 195, 196, 197)   # V transposed-read lane bases (db16 & 3), the V ring's LDS offset included
+V_DKO, V_DKO2 = 198, 199  # LDS-DMA per-lane source offsets of K rows (column half 0 / 1: + 128 bytes)
+V_DVO, V_DVO2 = 200, 201  # ... of V rows
+V_DQ = 202                # ... of Q rows (the second half rides in the scalar offset)
+V_QR = (203, 204)         # Q row-read lane bases in the wave's slice (even / odd 32-column step)
+V_MC = (205, 206, 207, 208)   # running row maximum in the exp2 domain (c * max), per 16-row block
+V_CO = (209, 210, 211, 212)   # rescale coefficient per 16-row block
+V_MX = (213, 214, 215, 216)   # row-max chain per 16-row block (one chain over both key halves)
+V_MSV = (217, 218, 219, 220)  # running maximum of the finished job
 V_LANE = 221
-V_EW = 222                # epilogue LDS write base (row i, +8h)
-V_ESW = 223               # (unused)
-V_ER = 224                # epilogue LDS read base
-V_EO = 225                # epilogue global store lane offset (os_n)
-V_L2 = 226                # L store lane offset
-V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), accumulators [3] (228..230)
-V_NINF = 231              # causal: -inf (a literal would be the second constant-bus operand beside VCC)
+V_T = tuple(range(222, 232))  # temporaries (V_T[0], V_T[2], ... even; V_T[2] = v224 is 4-aligned: a zero MFMA operand in the epilogue)
+V_ONES = 232              # 4 registers: the all-ones A operand of the row-sum MFMA
+V_LACC = (236, 240, 244, 248)  # row-sum accumulators per 16-row block (4 registers each, all equal: the lane's own row sum)
+V_NINF = 252              # causal / ragged: -inf
 NINF = V(V_NINF)
-V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
-V_LSV = (234, 235)        # [0]: read-back address of the epilogue; [1] = V_PM[5] in the causal kernels
-V_MSV = (236, 237)        # running maximum of the finished job
-V_ONES = 244              # 4 registers: the 0 / 1 A operand of the row-sum MFMA (v_mfma_f32_16x16x32)
-V_LACC = (248, 252)       # row-sum accumulators of the two query blocks (4 registers each; register 0 = the lane's own row)
-V_DQE, V_DQO = 240, 241   # LDS-DMA per-lane source offsets of the Q rows (row stride qs_n; even / odd 8-row group)
-V_QRE, V_QRO = 242, 243   # Q row-read lane bases in the wave's slice (even / odd k-step)
-V_IMH = 238               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
-V_PM = (200, 201, 202, 203, 220, 235, 221, 239)   # causal: AND masks of the eight packed P registers of a triangle group (221 =
-#                           V_LANE, dead after the set-up)
+V_IMH = 253               # causal: li - 4 g (query row inside a 16-row block minus the lane group's key offset)
+V_PM = (254, 255)         # causal: AND masks of the two packed P registers of a diagonal 16 x 16 block
+# during the epilogue (the row sums have been read, the accumulators are zeroed at its end) V_LACC[0..] hold its lane constants:
+V_EW, V_ER, V_EO, V_L2 = 236, 237, 238, 239   # LDS write base, LDS read base, global store lane offset, L store lane offset
 
 
 # AGPRs
-def A_O(qb, db):
-    return A((qb * 4 + db) * 16, 16)
+def A_O(qb16, db16):
+    return A((qb16 * 8 + db16) * 4, 4)
 
 
-def A_Q(qb, ks):
-    return A(128 + (qb * 8 + ks) * 4, 4)
+def A_Q(qb16, ks):
+    return A(128 + (qb16 * 4 + ks) * 4, 4)
 
 
-def A_K(kb, ks):
-    # the K tile lives in ARCH VGPRs v[128:191]: ds_read into accumulator registers while MFMAs write accumulators was
-    # measured 470 cycles per tile slower (and skews the four waves at the barrier)
-    return V(VF + (kb * 8 + ks) * 4, 4)
+def A_K(kb16, ks):
+    # the K tile lives in ARCH VGPRs v[128:191] (a64: LDS reads into accumulator registers while MFMAs write accumulators cost
+    # 470 cycles per tile)
+    return V(KF + (kb16 * 4 + ks) * 4, 4)
 
 
-def V_F(kstep, db):
+def V_F(kk, db16):
     # V^T fragments in a[192:255]: read in phase A, whose MFMAs (QK^T) write arch VGPRs
-    return A(192 + 4 * (4 * kstep + db), 4)
+    return A(192 + 4 * (8 * kk + db16), 4)
+
+
+def S_BLK(Y, kb16, qb16):
+    """accumulator of S^T(kb16, qb16) in score buffer Y"""
+    return V(Y + 16 * (2 * (qb16 >> 1) + (kb16 >> 1)) + 8 * (qb16 & 1) + 4 * (kb16 & 1), 4)
+
+
+def P_OP(X, qb16, kk):
+    """the packed P^T(qb16, kk): B operand of the second product (the first four registers of the group's 8-register half)"""
+    return V(X + 16 * (2 * (qb16 >> 1) + kk) + 8 * (qb16 & 1), 4)
 
 
 # SGPRs.  s4..s47 hold the kernel arguments (loaded once).
@@ -122,8 +123,16 @@ VBASE = 32768
 VB = (0, 16384)                  # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
 EPI = 65536                      # + 16384 * wave: the wave's private 64 x 256-byte slice: the next job's Q rows land here by
                                  # LDS-DMA (K-tile image) on their way to a[128:191]; later the job's O rows leave through it
-EPI_ROW = 272                    # (= 256 + 16, formed with shifts in k_setup) byte stride of an O row in the slice during the epilogue (k_setup)
+EPI_ROW = 272                    # (= 256 + 16) byte stride of an O row in the slice during the epilogue: 16-byte aligned for the row reads;
+                                 # the 8-byte column writes of a 16-lane group are 2-way conflicted (as in a64), the 16-byte row reads conflict-free
 LDS_TOTAL = 131072
+V_ST_LAST, V_ST_ACC = 252, 253   # diagnostic (stamps) builds, non-causal only: last stamp (low word), accumulators [3] (253..255)
+
+
+def tile_addr(row, c16):
+    """byte offset of 16-byte chunk c16 (0..15) of row `row` (0..63) inside a K / V / Q tile image: two column halves of
+    64 rows x 128 bytes, the eight chunks of a half row XOR-swizzled by (row & 6)"""
+    return 8192 * (c16 >> 3) + 128 * row + 16 * ((c16 & 7) ^ (row & 6))
 
 KARG_SIZE = 192
 NSLOT = 24
@@ -131,27 +140,33 @@ NSLOT = 24
 
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
-                 caps=(5, 24), split=True):
+                 caps=(5, 24), split=True, soft=None):
         assert dtype in ("bf16", "f16")
         self.dtype = dtype
         self.causal = causal
-        self.name = name or f"fa2_fwd_a64_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
+        self.name = name or f"fa2_fwd_a16_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
         self.atmp = 0          # (ragged) which of the two address temporaries the next buffer operation takes
         self.atmp_regs = (V_T[8], V_T[9])
         self.prog: list[Inst] = []
         self.uid = 0
-        self.mfma = "v_mfma_f32_32x32x16_" + dtype
+        self.mfma = "v_mfma_f32_16x16x32_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.ool: list[list[Inst]] = []  # out-of-line blocks (rare paths), appended after the main body
+        self.soft = soft       # (limit, window) of the softmax plan's soft per-gap issue limit, or None (tile_plan.place)
         self.caps = caps       # fillers / issue cycles a gap behind a 32x32x16 MFMA may carry in the softmax plan
         # causal row map "split": wave w owns the 32-row blocks w (qb 0) and w + 4 (qb 1) of the job's 256 rows instead of
         # 2 w and 2 w + 1.  Diagonal tile j (key blocks 2 j, 2 j + 1) is then hidden from query block 0 of EVERY wave for
         # j >= 2 and fully visible to query block 1 for j < 2: the job's last steps run on one query block (half the MFMAs)
         # for all four waves instead of on both for a shrinking set of waves -- see build()
+        assert split, "the a16 kernels use the split row map only"
         self.split = bool(split) and causal
         self.cls = None        # split seam bodies: "low" (waves 0, 1) / "high" (waves 2, 3) while their code is generated
         self.ragged = ragged   # N is not a multiple of 256: range-checked descriptors, every offset in the VGPR operand, masked key tail
         assert not (ragged and stamps), "the ragged kernels use the stamps' temporaries as address registers"
+        # (the accumulating stamps use the causal kernels' mask registers: causal diagnostic builds carry the plain job-timeline
+        # stamps only -- "noacc")
+        if stamps and causal:
+            abl = tuple(abl) + ("noacc",)
         self.vread_double = vread_double   # phase-A gaps that carry two V transposed reads (the last read sits in gap 31 - this)
         self.abl = set(abl)    # timing-only ablations of the steady loop (diagnostic builds; results wrong by construction)
         self.R, self.dk, self.dv = ring   # ring depth; K(t + dk) and V(t + dv) are streamed in phase B(t): dk <= R + 1, dv <= R
@@ -203,7 +218,7 @@ class Gen:
     def stamp_acc(self, k):
         """diagnostic builds only: acc[k] += cycles since the previous stamp_acc (its s_waitcnt drains the LDS queue as well: the
         per-phase shares cost cycles of their own -- the "lite" kernels carry the job-level stamps only)"""
-        if not self.stamps or "lite" in self.abl:
+        if not self.stamps or "lite" in self.abl or "noacc" in self.abl:
             return []
         t = S(S_T[0].idx, 2)
         tmp = V(V_T[9])
@@ -213,7 +228,7 @@ class Gen:
     def stamp_job(self, k):
         """lite diagnostic builds: acc[k] += cycles since the previous stamp_job, summed over ALL jobs of the workgroup
         (0 steady loops, 1 seam bodies, 2 epilogues + job bookkeeping, 3 the pipeline fill of the first job)"""
-        if not self.stamps or "lite" not in self.abl:
+        if not self.stamps or "lite" not in self.abl or "noacc" in self.abl:
             return []
         t = S(S_T[0].idx, 2)
         tmp = V(V_T[9])
@@ -221,7 +236,7 @@ class Gen:
         return [I("s_memtime", t), waitcnt(lgkmcnt=0)] + acc + [I("v_mov_b32", V(V_ST_LAST), t.sub(0))]
 
     def stamp_job_flush(self):
-        if not self.stamps or "lite" not in self.abl:
+        if not self.stamps or "lite" not in self.abl or "noacc" in self.abl:
             return []
         out = [I("v_mov_b32", V(V_T[7]), 0)]
         for k, slot in enumerate((10, 11, 12)):
@@ -229,7 +244,7 @@ class Gen:
         return out
 
     def stamp_flush(self):
-        if not self.stamps or "lite" in self.abl:
+        if not self.stamps or "lite" in self.abl or "noacc" in self.abl:
             return []
         out = [I("v_mov_b32", V(V_T[7]), 0)]
         for k in range(3):
@@ -296,84 +311,57 @@ class Gen:
           I("s_load_dwordx2", S_DBG, S_KARG, 176), I("s_load_dword", S_LG, S_KARG, 184))
         lane, t0, t1, t2, t3 = V(V_LANE), V(V_T[0]), V(V_T[1]), V(V_T[2]), V(V_T[3])
         e(I("v_and_b32", lane, 63, V(0)), I("v_lshrrev_b32", t0, 6, V(0)), I("s_nop", 1), I("v_readfirstlane_b32", S_WAVE, t0), I("s_nop", 4),
-          I("s_lshl_b32", S_LDSW, S_WAVE, 11))
-        # i = lane & 31, h = lane >> 5
-        # ---- K row-read bases: 2048 (i >> 3) + 64 (i & 7) + 16 ((2 e + h) ^ ((i >> 2) & 3))
+          I("s_lshl_b32", S_LDSW, S_WAVE, 10))
+        # lane = 16 g + li
+        # ---- K row-read bases (tile_addr): row 16 kb16 + li, chunk 4 ks + g:  128 li + 16 ((4 e + g) ^ (li & 6)), e = ks & 1
         e(comment("K row-read lane bases"),
-          I("v_and_b32", t0, 31, lane),                    # i
-          I("v_lshrrev_b32", t1, 3, t0), I("v_lshlrev_b32", t1, 11, t1),   # 2048 (i >> 3)
-          I("v_and_b32", t2, 7, t0), I("v_lshl_add_u32", t1, t2, 6, t1),   # + 64 (i & 7)
-          I("v_bfe_u32", t2, t0, 2, 2),                    # g = (i >> 2) & 3
-          I("v_lshrrev_b32", t3, 5, lane),                 # h
-          I("v_xor_b32", t2, t2, t3),                      # h ^ g          (even k-step: chunk slot (0 + h) ^ g)
-          I("v_lshl_add_u32", V(V_KRE), t2, 4, t1),
-          I("v_xor_b32", t2, 2, t2),                       # (2 + h) ^ g
-          I("v_lshl_add_u32", V(V_KRO), t2, 4, t1))
-        # ---- V transposed-read bases: VBASE + 64 (4 h + q) + 16 ((2 w + (p >> 1)) ^ ((2 u + h) & 3)) + 8 (p & 1)
-        #      w = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3
+          I("v_and_b32", t0, 15, lane),                    # li
+          I("v_lshrrev_b32", t1, 4, lane),                 # g
+          I("v_and_b32", t2, 6, t0),                       # li & 6
+          I("v_xor_b32", t2, t2, t1),                      # g ^ (li & 6)            (e = 0)
+          I("v_lshlrev_b32", t3, 7, t0),                   # 128 li
+          I("v_lshl_add_u32", V(V_KR[0]), t2, 4, t3),
+          I("v_xor_b32", t2, 4, t2),                       # (4 + g) ^ (li & 6)      (e = 1)
+          I("v_lshl_add_u32", V(V_KR[1]), t2, 4, t3))
+        # ---- V transposed-read bases: inside a 16-lane group lane li = 4 q + p supplies key row 4 g + q, columns 4 p .. 4 p + 3 of
+        #      the 16-column block db16:  VBASE + 128 (4 g + q) + 16 ((2 b + (p >> 1)) ^ (4 (g & 1) + (q & 2))) + 8 (p & 1), b = db16 & 3
         e(comment("V transposed-read lane bases"),
           I("v_bfe_u32", t0, lane, 2, 2),                  # q
-          I("v_lshrrev_b32", t3, 5, lane),                 # h
-          I("v_lshl_add_u32", t0, t3, 2, t0),              # 4 h + q
-          I("v_lshlrev_b32", t0, 6, t0),                   # 64 (4 h + q)
-          I("v_and_b32", t1, 1, lane), I("v_lshl_add_u32", t0, t1, 3, t0),  # + 8 (p & 1)
-          I("v_add_u32", t0, VBASE, t0),
-          I("v_bfe_u32", t1, lane, 4, 1), I("v_lshlrev_b32", t1, 1, t1),    # 2 w
-          I("v_bfe_u32", t2, lane, 1, 1), I("v_or_b32", t1, t1, t2),        # 2 w + (p >> 1)
-          I("v_xor_b32", t2, t1, t3),                      # u = 0: ^ h
-          I("v_lshl_add_u32", V(V_VR0), t2, 4, t0),
-          I("v_xor_b32", t2, 2, t2),                       # u = 1: ^ (2 + h)
-          I("v_lshl_add_u32", V(V_VR1), t2, 4, t0))
-        # ---- LDS-DMA lane source offsets: l' = lane & 31: row_in = l' >> 2, slot = l' & 3, sub = lane >> 5
-        #      chunk = 4 sub + (slot ^ (2 (wave & 1) + (l' >> 4)));  offset = row_in * stride + 16 chunk
+          I("v_lshrrev_b32", t1, 4, lane),                 # g
+          I("v_lshl_add_u32", t2, t1, 2, t0),              # 4 g + q
+          I("v_lshlrev_b32", t2, 7, t2),                   # 128 (4 g + q)
+          I("v_and_b32", t3, 1, lane), I("v_lshl_add_u32", t2, t3, 3, t2),   # + 8 (p & 1)
+          I("v_add_u32", t2, VBASE, t2),
+          I("v_and_b32", t1, 1, t1), I("v_lshlrev_b32", t1, 2, t1),          # 4 (g & 1)
+          I("v_and_b32", t0, 2, t0), I("v_or_b32", t1, t1, t0),              # + (q & 2)
+          I("v_bfe_u32", t0, lane, 1, 1), I("v_xor_b32", t1, t1, t0))        # ^ (p >> 1)          (b = 0)
+        for b in range(4):
+            e(I("v_xor_b32", t0, 2 * b, t1), I("v_lshl_add_u32", V(V_VR[b]), t0, 4, t2))
+        # ---- LDS-DMA lane source offsets: a piece is 8 rows x 128 bytes; lane i lands at row i >> 3, chunk position i & 7 of the
+        #      image, which holds source chunk (i & 7) ^ ((i >> 3) & 6):  offset = (i >> 3) * stride + 16 ((i & 7) ^ ((i >> 3) & 6))
         e(comment("LDS-DMA per-lane source offsets"),
-          I("v_and_b32", t0, 3, lane),                     # slot
-          I("v_bfe_u32", t1, lane, 4, 1),                  # l' >> 4
-          I("s_and_b32", S_T[0], S_WAVE, 1), I("s_lshl_b32", S_T[0], S_T[0], 1),
-          I("v_or_b32", t1, S_T[0], t1),
-          I("v_xor_b32", t0, t0, t1),
-          I("v_lshrrev_b32", t1, 5, lane), I("v_lshl_or_b32", t0, t1, 2, t0),   # 4 sub + ...
-          I("v_lshlrev_b32", t0, 4, t0),                   # 16 chunk
-          I("v_bfe_u32", t1, lane, 2, 3))                  # row_in
+          I("v_lshrrev_b32", t1, 3, lane),                 # row_in
+          I("v_and_b32", t0, 6, t1), I("v_and_b32", t2, 7, lane), I("v_xor_b32", t0, t0, t2),
+          I("v_lshlrev_b32", t0, 4, t0))                   # 16 chunk
         e(waitcnt(lgkmcnt=0, comment="kernel arguments are in"))
         e(I("v_mul_lo_u32", t2, t1, S_KSN), I("v_add_u32", V(V_DKO), t2, t0), I("v_add_u32", V(V_DKO2), 128, V(V_DKO)),
-          I("v_mul_lo_u32", t2, t1, S_VSN), I("v_add_u32", V(V_DVO), t2, t0), I("v_add_u32", V(V_DVO2), 128, V(V_DVO)))
-        # ---- Q rows: the same piece shape for the 8-row groups R = 0..7 of the wave's 64 rows; the slot XOR is 2 (R & 1) + (l' >> 4)
-        e(comment("Q staging: LDS-DMA lane offsets (even / odd row group) and row-read bases in the wave's slice"),
-          I("v_and_b32", t0, 3, lane), I("v_bfe_u32", t2, lane, 4, 1),
-          I("v_xor_b32", t3, t0, t2),                       # even R: slot ^ (l' >> 4)
-          I("v_lshrrev_b32", t2, 5, lane), I("v_lshl_or_b32", t3, t2, 2, t3), I("v_lshlrev_b32", t3, 4, t3),
-          I("v_mul_lo_u32", t2, t1, S_QSN), I("v_add_u32", V(V_DQE), t2, t3),
-          I("v_xor_b32", t3, 32, t3),                       # odd R: slot ^ (2 + (l' >> 4)): bit 1 of the slot = bit 5 of 16 * chunk
-          I("v_add_u32", V(V_DQO), t2, t3),
+          I("v_mul_lo_u32", t2, t1, S_VSN), I("v_add_u32", V(V_DVO), t2, t0), I("v_add_u32", V(V_DVO2), 128, V(V_DVO)),
+          I("v_mul_lo_u32", t2, t1, S_QSN), I("v_add_u32", V(V_DQ), t2, t0))
+        e(comment("Q row-read bases in the wave's slice"),
           I("s_lshl_b32", S_T[0], S_WAVE, 14), I("s_add_u32", S_T[0], S_T[0], EPI),
-          I("v_add_u32", V(V_QRE), S_T[0], V(V_KRE)), I("v_add_u32", V(V_QRO), S_T[0], V(V_KRO)))
-        # ---- epilogue: the wave's slice holds a query block's 32 O rows at a stride of EPI_ROW = 272 bytes (256 + 16: the
-        #      8-byte writes of a column group and the 16-byte row reads both spread over all banks, and every address is a lane
-        #      base plus an immediate).  Write base EPI + 16384 wave + 272 i + 8 h
-        e(comment("epilogue lane constants"),
-          I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane),
-          I("v_lshlrev_b32", t1, 8, t0), I("v_lshl_add_u32", t1, t0, 4, t1),    # 272 i
-          I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1))
-        # read-back: a = lane >> 4, ec = lane & 15: base + 272 a + 16 ec (+ 4 x 272 k: row 4 k + a); store offset a * os_n + 16 ec
-        e(I("v_lshrrev_b32", t0, 4, lane), I("v_and_b32", t1, 15, lane),
-          I("v_lshlrev_b32", t2, 8, t0), I("v_lshl_add_u32", t2, t0, 4, t2),    # 272 a
-          I("v_lshl_add_u32", t2, t1, 4, t2), I("v_add_u32", V(V_ER), S_T[0], t2),
-          I("v_mul_lo_u32", t2, t0, S_OSN), I("v_lshl_add_u32", V(V_EO), t1, 4, t2),
-          I("v_and_b32", t0, 31, lane), I("v_lshlrev_b32", V(V_L2), 1, t0))
+          I("v_add_u32", V(V_QR[0]), S_T[0], V(V_KR[0])), I("v_add_u32", V(V_QR[1]), S_T[0], V(V_KR[1])))
         if self.stamps:
             e(I("s_lshl_b32", S_T[0], S_WGID, 2), I("s_add_u32", S_T[0], S_T[0], S_WAVE), I("s_mul_i32", S_T[0], S_T[0], 8 * NSLOT),
               I("s_add_u32", S_DBG.sub(0), S_DBG.sub(0), S_T[0]), I("s_addc_u32", S_DBG.sub(1), S_DBG.sub(1), 0))
             e(self.stamp(6, real=True), self.stamp(8))
-            e([I("v_mov_b32", V(V_ST_ACC + k), 0) for k in range(3)], I("v_mov_b32", V(V_ST_LAST), 0))
-        # ---- row sums on the matrix pipe: the 0 / 1 operand (lanes with (lane & 7) == 4 * ((lane >> 4) & 1) hold ones), accumulators
+            if "noacc" not in self.abl:
+                e([I("v_mov_b32", V(V_ST_ACC + k), 0) for k in range(3)], I("v_mov_b32", V(V_ST_LAST), 0))
+        # ---- row sums on the matrix pipe: the all-ones operand, accumulators; rescale factors
         one2 = 0x3F803F80 if self.dtype == "bf16" else 0x3C003C00
-        e(comment("row-sum MFMA operand, accumulators, rescale factors"),
-          I("v_bfe_u32", t1, lane, 4, 1), I("v_lshlrev_b32", t1, 2, t1), I("v_and_b32", t0, 7, lane),
-          I("v_cmp_eq_u32", VCC, t0, t1), I("v_mov_b32", t2, one2))
-        e([I("v_cndmask_b32", V(V_ONES + k), 0, t2, VCC) for k in range(4)])
-        e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
-        e([I("v_mov_b32", V(V_CO[qb]), 1.0) for qb in range(2)])
+        e(comment("row-sum MFMA operand, accumulators, rescale factors"))
+        e([I("v_mov_b32", V(V_ONES + k), one2) for k in range(4)])
+        e([I("v_mov_b32", V(V_LACC[q] + k), 0) for q in range(4) for k in range(4)])
+        e([I("v_mov_b32", V(V_CO[q]), 1.0) for q in range(4)])
         # ---- scalar constants
         e(I("s_lshl_b32", S_K32, S_KSN, 5), I("s_lshl_b32", S_V32, S_VSN, 5),
           I("s_lshl_b32", S_K64, S_KSN, 6), I("s_lshl_b32", S_V64, S_VSN, 6),
@@ -386,17 +374,30 @@ class Gen:
               I("v_mov_b32", NINF, float("-inf")))
         if self.causal:
             e(comment("causal: lane constants of the diagonal mask"),
-              I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
-              I("v_sub_u32", V(V_IMH), t0, t3),   # i - 4 h
+              I("v_and_b32", t0, 15, lane), I("v_lshrrev_b32", t3, 4, lane), I("v_lshlrev_b32", t3, 2, t3),
+              I("v_sub_u32", V(V_IMH), t0, t3),   # li - 4 g
               I("v_mov_b32", NINF, float("-inf")))
             e(I("v_mov_b32", V(V_T[4]), 0xFFFF0000), I("v_mov_b32", V(V_T[5]), 0x0000FFFF))
-            # packed P register j of a triangle group holds keys k0 = 2 (j & 1) + 8 (j >> 1) + 4 h and k0 + 1 of query i:
-            # keep both (k0 + 1 <= i), the low one only (k0 == i) or none
-            for j in range(8):
-                k0 = 2 * (j & 1) + 8 * (j >> 1)
+            # packed P register jj (0, 1) of a diagonal 16 x 16 block holds keys k0 = 2 jj + 4 g and k0 + 1 of query li:
+            # keep both (k0 + 1 <= li), the low one only (k0 == li) or none
+            for jj in range(2):
+                k0 = 2 * jj
                 e(I("v_cmp_ge_i32", VCC, V(V_IMH), k0 + 1), I("v_cndmask_b32", t1, 0, V(V_T[4]), VCC),
                   I("v_cmp_ge_i32", VCC, V(V_IMH), k0), I("v_cndmask_b32", t2, 0, V(V_T[5]), VCC),
-                  I("v_or_b32", V(V_PM[j]), t1, t2))
+                  I("v_or_b32", V(V_PM[jj]), t1, t2))
+
+    def k_epi_consts(self):
+        """lane constants of the epilogue, formed at its start in the (read-out) row-sum accumulators: the slice holds a query
+        block's 32 O rows at a stride of EPI_ROW bytes.  Write base (row li, + 8 g): slice + EPI_ROW li + 8 g;  read-back
+        (a = lane >> 4, ec = lane & 15): slice + EPI_ROW a + 16 ec (+ 4 EPI_ROW k: row 4 k + a); store offset a * os_n + 16 ec"""
+        lane = V(V_LANE)
+        t0, t1, t2 = V(V_LACC[1]), V(V_LACC[1] + 1), V(V_LACC[1] + 2)
+        return [I("s_lshl_b32", S_X2, S_WAVE, 14), I("s_add_u32", S_X2, S_X2, EPI),
+                I("v_and_b32", t0, 15, lane), I("v_lshrrev_b32", t1, 4, lane),
+                I("v_mul_u32_u24", t2, EPI_ROW, t0), I("v_lshl_add_u32", t2, t1, 3, t2), I("v_add_u32", V(V_EW), S_X2, t2),
+                I("v_mul_u32_u24", t2, EPI_ROW, t1), I("v_lshl_add_u32", t2, t0, 4, t2), I("v_add_u32", V(V_ER), S_X2, t2),
+                I("v_mul_lo_u32", t2, t1, S_OSN), I("v_lshl_add_u32", V(V_EO), t0, 4, t2),
+                I("v_lshlrev_b32", V(V_L2), 1, t0)]
 
     # ------------------------------------------------------------------ job decode: S_JOB (+ S_PASS) -> S_NB, S_NHH, S_NQI, S_NNT
     def k_decode_next(self, vt=None):
@@ -479,7 +480,8 @@ class Gen:
     # ------------------------------------------------------------------ LDS-DMA
     def dma_piece(self, which, piece, buf):
         """one 1-KiB LDS-DMA piece of the next K / V tile into ring buffer `buf`.  piece j: rows 8 R .. 8 R + 7 with
-        R = wave (j < 2) or wave + 4, 128-byte half j & 1 (the +128 rides in the second lane-offset register)"""
+        R = wave (j < 2) or wave + 4, 128-byte column half j & 1 (the +128 rides in the second lane-offset register); it lands at
+        8192 (j & 1) + 1024 R of the tile image (tile_addr)"""
         if which == "k":
             rsrc, vl, vl2, base, s32, lds0 = S_KRS, V(V_DKO), V(V_DKO2), S_KDMA, S_K32, KB[buf]
         else:
@@ -489,7 +491,7 @@ class Gen:
         if piece >= 2:
             so = S_T[5]
             out.append(I("s_add_u32", so, base, s32))
-        out.append(I("s_add_u32", M0, S_LDSW, lds0 + (0, 1024, 8192, 9216)[piece]))
+        out.append(I("s_add_u32", M0, S_LDSW, lds0 + (0, 8192, 4096, 12288)[piece]))
         pre, ld = self.buf_op("buffer_load_dwordx4", None, vl2 if piece & 1 else vl, rsrc, so, lds=1, tag=f"dma {which}{piece}")
         return out + pre + [I("s_nop", 0), ld]
 
@@ -501,9 +503,8 @@ class Gen:
         return out
 
     def q_stage(self, b: Reg, hh: Reg, qi: Reg):
-        """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the K-tile image (16 pieces of 8 rows x
-        128 bytes: coalesced, ~25 cycles of issue each; the same rows fetched straight into the MFMA operand layout -- 32 rows x
-        32 bytes per instruction -- cost ~210 cycles per load).  Returns (descriptor / offset setup, [pieces])"""
+        """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the tile image (16 pieces of 8 rows x
+        128 bytes: coalesced, ~25 cycles of issue each).  Returns (descriptor / offset setup, [pieces])"""
         setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh, S_QSN)
         setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 5 if self.split else 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
                   I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
@@ -523,54 +524,53 @@ class Gen:
                     pc.append(I("s_add_u32", so, S_T[2], 128))
                     if R < 7:
                         pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
-                pc.append(I("s_add_u32", M0, S_T[4], 2048 * R + 1024 * half))
-                pre, ld = self.buf_op("buffer_load_dwordx4", None, V(V_DQO if R & 1 else V_DQE), S_SQ, so, lds=1, tag=f"qdma R{R} h{half}")
+                pc.append(I("s_add_u32", M0, S_T[4], 1024 * R + 8192 * half))
+                pre, ld = self.buf_op("buffer_load_dwordx4", None, V(V_DQ), S_SQ, so, lds=1, tag=f"qdma R{R} h{half}")
                 pieces.append((pc + pre, ld))
         return setup, pieces
 
     def q_reads(self):
-        """the staged Q rows -> a[128:191] (fragment (qb, ks) = rows 32 qb + i, 16-byte chunk 2 ks + h, as a K row read)"""
+        """the staged Q rows -> a[128:191] (fragment (qb16, ks) = rows 16 qb16 + li, 16-byte chunk 4 ks + g, as a K row read)"""
         out = []
-        for qb in range(2):
-            for ks in range(8):
-                out.append(I("ds_read_b128", A_Q(qb, ks), V(V_QRO if ks & 1 else V_QRE), offset=8192 * qb + 512 * (ks >> 1), tag=f"qread qb{qb} ks{ks}"))
+        for qb16 in range(4):
+            for ks in range(4):
+                out.append(I("ds_read_b128", A_Q(qb16, ks), V(V_QR[ks & 1]), offset=2048 * qb16 + 8192 * (ks >> 1), tag=f"qread qb{qb16} ks{ks}"))
         return out
 
     # ------------------------------------------------------------------ the two phases
     def qk_mfmas(self, Y, cinit=None, qbs=(0, 1)):
-        """S^T(next) chains g = 2 qb + kb into score buffer Y.  cinit[g]: None -> C = 0, Reg -> C operand of the first MFMA.
-        qbs: the query blocks whose chains are computed -- the others' MFMAs are None in the returned list (emit_phase)"""
+        """S^T(next) into score buffer Y as 32 SLOTS of two MFMAs: slot (qh, kb16, ks) = the blocks qb16 = 2 qh, 2 qh + 1 against
+        K(kb16, ks) -- consecutive MFMAs share their A operand; an accumulator is revisited every second MFMA.
+        qbs: the query blocks qh whose scores are computed -- the others' slots are None in the returned list (emit_phase)"""
+        assert cinit is None
         out = []
-        if "qk_chain_order" in self.abl:     # (the round's first order: one chain after the other)
-            order = [(g, ks) for g in range(4) for ks in range(8)]
-        else:
-            # the two chains of a query block interleaved: consecutive MFMAs share their B operand (the Q fragment) -- half the
-            # operand toggling of the matrix pipe's inputs, and no MFMA follows the one it accumulates onto
-            order = [(2 * qb + kb, ks) for qb in range(2) for ks in range(8) for kb in range(2)]
-        for g, ks in order:
-            qb, kb = g >> 1, g & 1
-            d = V(Y + 16 * g, 16)
-            c = d if ks else (cinit[g] if cinit and cinit[g] is not None else 0)
-            out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}") if qb in qbs else None)
+        for qh in range(2):
+            for kb16 in range(4):
+                for ks in range(4):
+                    pair = []
+                    for qb16 in (2 * qh, 2 * qh + 1):
+                        d = S_BLK(Y, kb16, qb16)
+                        pair.append(I(self.mfma, d, A_K(kb16, ks), A_Q(qb16, ks), d if ks else 0, tag=f"qk qb{qb16} kb{kb16} ks{ks}"))
+                    out.append(pair if qh in qbs else None)
         return out
 
     def v_reads(self, buf):
-        """32 transposed reads of the V tile in VB[buf]: fragment (kstep, db) <- u = 0, 1"""
+        """32 transposed reads of the V tile in VB[buf]: fragment (kk, db16) <- u = 0, 1 (keys 32 kk + 16 u + 4 g + 0..3)"""
         out = []
-        for kstep in range(4):
-            for db in range(4):
-                f = V_F(kstep, db)
+        for kk in range(2):
+            for db16 in range(8):
+                f = V_F(kk, db16)
                 for u in range(2):
-                    imm = VB[buf] + 2048 * (2 * kstep + u) + 512 * db
-                    out.append(I("ds_read_b64_tr_b16", f.sub(2 * u, 2), V(V_VR1 if u else V_VR0), offset=imm, tag=f"vread ks{kstep} db{db}"))
+                    imm = VB[buf] + 8192 * (db16 >> 2) + 4096 * kk + 2048 * u
+                    out.append(I("ds_read_b64_tr_b16", f.sub(2 * u, 2), V(V_VR[db16 & 3]), offset=imm, tag=f"vread kk{kk} db{db16}"))
         return out
 
     def k_reads(self, buf):
         out = []
-        for kb in range(2):
-            for ks in range(8):
-                imm = KB[buf] + 8192 * kb + 512 * (ks >> 1)
-                out.append(I("ds_read_b128", A_K(kb, ks), V(V_KRO if ks & 1 else V_KRE), offset=imm, tag=f"kread kb{kb} ks{ks}"))
+        for kb16 in range(4):
+            for ks in range(4):
+                imm = KB[buf] + 2048 * kb16 + 8192 * (ks >> 1)
+                out.append(I("ds_read_b128", A_K(kb16, ks), V(V_KR[ks & 1]), offset=imm, tag=f"kread kb{kb16} ks{ks}"))
         return out
 
     # ------------------------------------------------------------------ the softmax of one tile as a list of placed operations
@@ -616,6 +616,18 @@ class Gen:
 
         def place(earliest, c, kind, payload, is_exp=False):
             t = int(earliest)
+            # a pair of 16x16x32 MFMAs hides ~16 issue cycles of fillers, not the 24 a 32x32x16 MFMA does: prefer, within a few
+            # gaps of the earliest one, a gap that stays under the soft limit (the hard capacities still bound every gap)
+            if self.soft is not None:
+                lim, win = self.soft
+                for tt in range(t, t + win + 1):
+                    g = tt % P
+                    if tt < self.T_END and slots[g] + 1 <= cap_s[g] and cost[g] + c <= min(lim, cap_c[g]) and (not is_exp or nexp[g] < 2):
+                        slots[g] += 1
+                        cost[g] += c
+                        nexp[g] += int(is_exp)
+                        placed.append((tt, kind, payload))
+                        return tt
             while True:
                 assert t < self.T_END + 40, (kind, payload)
                 g = t % P
@@ -626,11 +638,14 @@ class Gen:
                     placed.append((t, kind, payload))
                     return t
                 t += 1
-        # row maxima: chain g may start 3 gaps after its last QK^T MFMA (12 wait states), one operation per gap and chain
+        # row maxima: the scores of group gi = 2 qh + kk are complete behind slot 16 qh + 8 kk + 7 (key blocks 2 kk, 2 kk + 1 of
+        # query block qh); their maxima may start 4 slots later (12 wait states behind the last MFMA), one operation per gap.
+        # One chain per 16-row block runs over both key halves: group (qh, 1) continues where (qh, 0) ended
         t_mx = {}
         for g in range(4):
-            # (chain g's last MFMA is number 8 g + 7, or 16 qb + 14 + kb with the chains of a query block interleaved)
-            t = 8 * g + 11 if "qk_chain_order" in self.abl else 16 * (g >> 1) + 18 + (g & 1)
+            t = 16 * (g >> 1) + 8 * (g & 1) + 11
+            if g & 1:
+                t = max(t, t_mx[g - 1])
             for j in range(8):
                 t = place(t, 5, "mx", (g, j)) + 1
             t_mx[g] = t
@@ -646,7 +661,7 @@ class Gen:
                 # gaps in front of the mid-step barrier; now its branch is the first thing behind the barrier)
                 # (not where the lazy masking of the contiguous row map / the ragged key tail pins 'mr' in front of the last packs)
                 gap2 = part == 4 and "fire_adjacent" not in self.abl and (self.split or not (self.causal or self.ragged))
-                t = place(t + (1 if gap2 else 0), (9, 5, 9, 4, 2)[part], "dec", (qb, part)) + 1
+                t = place(t + (1 if gap2 else 0), (2, 2, 13, 4, 2)[part], "dec", (qb, part)) + 1
             t_dec[qb] = t
         # (causal diagonal tiles handled lazily -- mask_lazy -- add four small operations at LAZY_TAU: gaps of phase A that are
         # nearly empty in every tile, so the plan itself does not reserve anything for them)
@@ -725,58 +740,65 @@ class Gen:
             return self.mask_lazy(Sb, kind, payload, lazy)
         if kind == "mx":
             g, j = payload
-            qb, kb = g >> 1, g & 1
-            mx = V(V_MX[qb][kb])
-            y = lambda r: V(Sb + 16 * g + r)
-            if j == 0:
+            qh, kk = g >> 1, g & 1
+            q1, jj = j >> 2, j & 3
+            mx = V(V_MX[2 * qh + q1])
+            y = lambda r: V(Sb + 16 * g + 8 * q1 + r)     # the block's eight scores of this key half
+            if kk:      # (the chain of the first key half goes on)
+                return [I("v_max3_f32", mx, mx, y(2 * jj), y(2 * jj + 1), tag=f"max g{g}")]
+            if jj == 0:
                 return [I("v_max3_f32", mx, y(0), y(1), y(2), tag=f"max g{g}")]
-            if j == 7:
-                return [I("v_max_f32", mx, mx, y(15), tag=f"max g{g}")]
-            return [I("v_max3_f32", mx, mx, y(2 * j + 1), y(2 * j + 2), tag=f"max g{g}")]
+            if jj == 3:
+                return [I("v_max_f32", mx, mx, y(7), tag=f"max g{g}")]
+            return [I("v_max3_f32", mx, mx, y(2 * jj + 1), y(2 * jj + 2), tag=f"max g{g}")]
         if kind == "dec":
-            qb, part = payload
-            a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
-            d = V(V_T[qb])
-            # A row's 64 scores of a tile sit in two lanes (h = 0, 1).  Whether the running maximum must move is decided on the
-            # lanes' PARTIAL maxima: some lane exceeds the threshold exactly when the row's maximum does -- so the exchange with
-            # lane ^ 32 (move, swap, max: three operations per query block and tile) happens only where the complete maximum is
-            # used: in a job's first tile (it sets m) and at the head of the rare firing path.  "full_max": the exchange in
-            # every tile, as until the end of round 2 (A/B variant)
-            full = init or "full_max" in self.abl
-            if part == 0:
-                return [I("v_max_f32", a, a, b)] + ([I("v_mov_b32", b, a)] if full else [])
-            if part == 1:
-                return [I("v_permlane32_swap_b32", a, b)] if full else []
+            qh, part = payload
+            qs = (2 * qh, 2 * qh + 1)
+            a = [V(V_MX[q]) for q in qs]
+            d = V(V_T[qh])
+            b = [V(V_T[2 + 2 * qh]), V(V_T[3 + 2 * qh])]
+            # A row's 64 scores of a tile sit in four lanes (g = 0..3).  Whether the running maximum must move is decided on the
+            # lanes' PARTIAL maxima: some lane exceeds the threshold exactly when the row's maximum does -- so the exchanges with
+            # lanes ^ 16 and ^ 32 happen only where the complete maximum is used: in a job's first tile (it sets m) and at the
+            # head of the rare firing path.
+            def row_max(x, tmp):
+                return [I("v_mov_b32", tmp, x), I("v_permlane16_swap_b32", x, tmp), I("v_max_f32", x, x, tmp),
+                        I("v_mov_b32", tmp, x), I("v_permlane32_swap_b32", x, tmp), I("v_max_f32", x, x, tmp)]
+            if part in (0, 1):
+                return []
             if part == 2:
                 if init:
-                    return [I("v_max_f32", a, a, b), I("v_mul_f32", V(V_MC[qb]), S_C, a)]
-                return ([I("v_max_f32", a, a, b)] if full else []) + [I("v_fma_f32", d, a, S_C, -V(V_MC[qb]))]
+                    return row_max(a[0], b[0]) + row_max(a[1], b[1]) + [I("v_mul_f32", V(V_MC[q]), S_C, a[k]) for k, q in enumerate(qs)]
+                return [I("v_fma_f32", d, a[0], S_C, -V(V_MC[qs[0]])), I("v_fma_f32", b[0], a[1], S_C, -V(V_MC[qs[1]])),
+                        I("v_max_f32", d, d, b[0])]
             if init:
                 return []
             if part == 3:
-                return [I("v_cmp_gt_f32", S_FIRE[qb], d, S_THR)]
+                return [I("v_cmp_gt_f32", S_FIRE[qh], d, S_THR)]
             if "fire_nobranch" in self.abl:       # (timing-only: the compare without its branch)
                 return []
             l_fire, l_back = self.lab("fire"), self.lab("fire_back")
-            # rare: raise this query block's running maximum now (every s' = s * c - m of the PREVIOUS tile has been formed:
-            # plan order), remember the factor; O and the row sums are scaled at the end of the coming phase B
-            t2, t3 = V(V_T[2 + 2 * qb]), V(V_T[3 + 2 * qb])
-            exact = self.fire_exact(Sb, qb, lazy) if lazy is not None else []
-            swap = [] if "full_max" in self.abl else [I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b)]
-            self.ool.append([label(l_fire)] + exact + swap + [I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
-                             I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
-                             I("s_or_b32", S_FLAG, S_FLAG, 1 << qb), I("s_branch", Label(l_back))])
-            return [I("s_cmp_lg_u64", S_FIRE[qb], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
+            # rare: raise this query block's running maxima now (every s' = s * c - m of the PREVIOUS tile has been formed:
+            # plan order), remember the factors; O and the row sums are scaled at the end of the coming phase B
+            exact = self.fire_exact(Sb, qh, lazy) if lazy is not None else []
+            blk = [label(l_fire)] + exact
+            for k, q in enumerate(qs):
+                t2, t3 = b[1], d
+                blk += row_max(a[k], b[0]) + [I("v_mul_f32", t2, S_C, a[k]), I("v_max_f32", t2, t2, V(V_MC[q])),
+                                              I("v_sub_f32", t3, V(V_MC[q]), t2), I("v_mov_b32", V(V_MC[q]), t2), I("v_exp_f32", V(V_CO[q]), t3)]
+            self.ool.append(blk + [I("s_or_b32", S_FLAG, S_FLAG, 1 << qh), I("s_branch", Label(l_back))])
+            return [I("s_cmp_lg_u64", S_FIRE[qh], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
         if kind == "f":
             e = payload
             y = V(Sb + e)
-            return [I("v_fma_f32", y, y, S_C, -V(V_MC[e >> 5]), tag=f"fma {e}")]
+            return [I("v_fma_f32", y, y, S_C, -V(V_MC[2 * (e >> 5) + ((e >> 3) & 1)]), tag=f"fma {e}")]
         if kind == "e":
             y = V(Sb + payload)
             return [I("v_exp_f32", y, y, tag=f"exp {payload}")]
         if kind == "cv":
             g, j = payload
-            return [I(self.cvt, V(Sb + 16 * g + j), V(Sb + 16 * g + 2 * j), V(Sb + 16 * g + 2 * j + 1), tag=f"cvt g{g} {j}")]
+            # (in place: the 8 scores of a block's key half -> its first four registers, the B operand P^T(qb16, kk))
+            return [I(self.cvt, V(Sb + 16 * g + 8 * (j >> 2) + (j & 3)), V(Sb + 16 * g + 2 * j), V(Sb + 16 * g + 2 * j + 1), tag=f"cvt g{g} {j}")]
         raise KeyError(kind)
 
     @staticmethod
@@ -836,73 +858,45 @@ class Gen:
         return out
 
     # ------------------------------------------------------------------ causal masks
-    def score_mask_ops(self, Y, g):
-        """the wave ON the diagonal (w == jd): -inf into the scores of group g = 2 qb + kb whose key lies behind the query.
-        (qb0, kb0) and (qb1, kb1) get the triangle, (qb0, kb1) is masked entirely, (qb1, kb0) not at all.  Register r of a
-        group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i"""
-        if g in (0, 3):
-            out = []
-            for r in range(16):
-                key = (r & 3) + 8 * (r >> 2)
-                out += [I("v_cmp_ge_i32", VCC, V(V_IMH), key), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
-            return out
-        if g == 1:
-            return [I("v_mov_b32", V(Y + 16 + r), NINF) for r in range(16)]
-        return []
-
     def group_mask_ops(self, Y, g, what):
-        """-inf into the scores of group g: what = "tri" (key block == query block: keys behind the query) or "all".
-        Register r of a group <-> key (r & 3) + 8 (r >> 2) + 4 h, lane <-> query i"""
+        """-inf into the scores of group g = 2 qh + kk (32 rows x 32 keys: register 8 q' + 4 k' + rr <-> row 16 q' + li, key
+        16 k' + 4 g_l + rr): what = "all", or "tri" (the key half is the query block's own: keys behind the query) -- sub-block
+        (q', k') = (0, 0) and (1, 1) get the 16 x 16 triangle (keep rr <= li - 4 g_l = V_IMH), (0, 1) goes entirely, (1, 0) stays"""
         if what == "all":
             return [I("v_mov_b32", V(Y + 16 * g + r), NINF) for r in range(16)]
         out = []
-        for r in range(16):
-            key = (r & 3) + 8 * (r >> 2)
-            out += [I("v_cmp_ge_i32", VCC, V(V_IMH), key), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
+        for q1 in range(2):
+            for rr in range(4):
+                y = V(Y + 16 * g + 8 * q1 + 4 * q1 + rr)       # sub-block (q', k' = q')
+                out += [I("v_cmp_ge_i32", VCC, V(V_IMH), rr), I("v_cndmask_b32", y, NINF, y, VCC)]
+        out += [I("v_mov_b32", V(Y + 16 * g + 4 + rr), NINF) for rr in range(4)]   # (0, 1)
         return out
 
     def mask_lazy(self, Sb, kind, payload, lazy):
         """Diagonal tiles other than a job's first are not masked before the softmax: the row maxima are taken over all 64 keys
         (a masked key can only RAISE a maximum: harmless unless it fires the deferred-maximum rescale, and that path --
         fire_exact -- masks the scores exactly and takes the maxima again), and
-          'pm'  the wave on the diagonal clears the masked entries of the PACKED P (24 instructions out of line instead of 80
-                on the fp32 scores: 8 AND masks per triangle group from the set-up, 8 zero moves for the hidden group);
-          'ms'  waves below the diagonal (the whole tile is hidden from them) swap +inf in for the running maximum of the
-                query block, so that every exp2(s c - m) is 0 and nothing fires;  'mr' puts the maximum back.
-        Both are in line, wave-uniform selects instead of branches (a taken branch costs ~25 cycles at one wave per SIMD)."""
+          'pm'  the wave on the diagonal clears the masked entries of the PACKED P (AND masks from the set-up for the two packed
+                registers of a 16 x 16 triangle, zero moves for what is hidden).
+        Every wave of this body sits on the diagonal of tile jd (tile_fill adds 'pm' only there): the even wave has pattern D0 on
+        query block qa = jd >> 1 (key half 0: triangle, key half 1: hidden), the odd one D1 (key half 0 visible, key half 1:
+        triangle).  D0 in line, D1 out of line (a taken branch costs what eight VALU operations do).  Packed register 8 q' + jj of
+        a group: rows 16 q' + li, keys 16 (jj >> 1) + 4 g_l + 2 (jj & 1), + 1"""
         jd, cond = lazy
-        if self.split:
-            # every wave of this body sits on the diagonal of tile jd (tile_fill adds 'pm' only there): the even wave has
-            # pattern D0 on query block qa = jd >> 1 (key block 0: triangle, key block 1: hidden), the odd one D1 (key block 0
-            # visible, key block 1: triangle).  D0 in line, D1 out of line (a taken branch costs what eight VALU operations do)
-            assert kind == "pm"
-            qa = jd >> 1
-            g0, g1 = 2 * qa, 2 * qa + 1
-            l_d1, l_back, l_skip = self.lab("pmask_d1"), self.lab("pmask_back"), self.lab("pmask_skip")
-            self.ool.append([label(l_d1)] + [I("v_and_b32", V(Sb + 16 * g1 + j), V(Sb + 16 * g1 + j), V(V_PM[j])) for j in range(8)] +
-                            [I("s_branch", Label(l_back))])
-            head = [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_skip))] if cond is not None else []
-            return head + [I("s_bitcmp1_b32", S_WAVE, 0), I("s_cbranch_scc1", Label(l_d1))] + \
-                [I("v_and_b32", V(Sb + 16 * g0 + j), V(Sb + 16 * g0 + j), V(V_PM[j])) for j in range(8)] + \
-                [I("v_mov_b32", V(Sb + 16 * g1 + j), 0) for j in range(8)] + [label(l_back)] + ([label(l_skip)] if cond is not None else [])
-        if kind == "pm":
-            l_pm, l_back = self.lab("pmask"), self.lab("pmask_back")
-            blk = [label(l_pm)]
-            if cond is not None:
-                blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_back))]
-            for g in (0, 3):
-                blk += [I("v_and_b32", V(Sb + 16 * g + j), V(Sb + 16 * g + j), V(V_PM[j])) for j in range(8)]
-            blk += [I("v_mov_b32", V(Sb + 16 + j), 0) for j in range(8)]
-            self.ool.append(blk + [I("s_branch", Label(l_back))])
-            return [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_pm)), label(l_back)]
-        if jd == 0:
-            return []      # no wave lies below diagonal tile 0
-        assert cond is None
-        sel = [I("s_cmp_ge_u32", S_WAVE, jd), I("s_cselect_b64", VCC, -1, 0)]   # VCC: the tile is (partly) visible to this wave
-        if kind == "ms":
-            qb = payload
-            return sel + [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])), I("v_cndmask_b32", V(V_MC[qb]), -NINF, V(V_MC[qb]), VCC)]
-        return sel + [I("v_cndmask_b32", V(V_MC[qb]), V(V_MSV[qb]), V(V_MC[qb]), VCC) for qb in range(2)]
+        assert self.split and kind == "pm"
+        qa = jd >> 1
+        g0, g1 = 2 * qa, 2 * qa + 1
+
+        def tri(g):
+            p = lambda q1, jj: V(Sb + 16 * g + 8 * q1 + jj)
+            return [I("v_and_b32", p(q1, 2 * q1 + jj), p(q1, 2 * q1 + jj), V(V_PM[jj])) for q1 in range(2) for jj in range(2)] + \
+                [I("v_mov_b32", p(0, 2 + jj), 0) for jj in range(2)]
+        l_d1, l_back, l_skip = self.lab("pmask_d1"), self.lab("pmask_back"), self.lab("pmask_skip")
+        self.ool.append([label(l_d1)] + tri(g1) + [I("s_branch", Label(l_back))])
+        head = [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_skip))] if cond is not None else []
+        return head + [I("s_bitcmp1_b32", S_WAVE, 0), I("s_cbranch_scc1", Label(l_d1))] + tri(g0) + \
+            [I("v_mov_b32", V(Sb + 16 * g1 + 8 * q1 + jj), 0) for q1 in range(2) for jj in range(4)] + [label(l_back)] + \
+            ([label(l_skip)] if cond is not None else [])
 
     def mask_tail(self, Sb, kind, payload, j, cond):
         """non-causal ragged, seam tile j (keys 64 j .. 64 j + 63 of the job's last 256; S_KT0 of them are real): a tile wholly
@@ -939,41 +933,30 @@ class Gen:
         return [I("s_cmp_lt_i32", S_KT0, 64 * j + 32 * kb + 32), I("s_cbranch_scc1", Label(l_m)), label(l_back)]
 
     def fire_exact(self, Sb, qb, lazy):
-        """head of the rare rescale path of a lazily masked diagonal tile: on the wave that sits on the diagonal the row maxima
-        were taken over masked keys too -- mask this query block's scores now and take the maxima again (then the plain path
-        decides with the exact maximum; the packed-P masking later is a no-op on the -inf entries)"""
+        """head of the rare rescale path of a lazily masked diagonal tile: on the waves that sit on the diagonal the row maxima
+        were taken over masked keys too -- mask this query block's scores now and take the maxima of its two 16-row blocks again
+        (then the plain path decides with the exact maxima; the packed-P masking later is a no-op on the -inf entries).
+        Only query block jd >> 1 has waves on the diagonal of tile jd: waves 2 p (pattern D0) and 2 p + 1 (D1), p = jd & 1"""
         jd, cond = lazy
+        assert self.split
+        if qb != jd >> 1:
+            return []
         l_plain = self.lab("fire_plain")
-        a, b = V(V_MX[qb][0]), V(V_MX[qb][1])
         blk = []
-        if self.split:
-            # only query block jd >> 1 has waves on the diagonal of tile jd: waves 2 p (pattern D0) and 2 p + 1 (D1), p = jd & 1
-            if qb != jd >> 1:
-                return []
-            p2 = 2 * (jd & 1)
-            l_d1, l_max = self.lab("fire_d1"), self.lab("fire_max")
-            if cond is not None:
-                blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_plain))]
-            blk += [I("s_cmp_eq_u32", S_WAVE, p2 + 1), I("s_cbranch_scc1", Label(l_d1)),
-                    I("s_cmp_eq_u32", S_WAVE, p2), I("s_cbranch_scc0", Label(l_plain))]
-            blk += self.group_mask_ops(Sb, 2 * qb, "tri") + self.group_mask_ops(Sb, 2 * qb + 1, "all") + [I("s_branch", Label(l_max))]
-            blk += [label(l_d1)] + self.group_mask_ops(Sb, 2 * qb + 1, "tri") + [label(l_max)]
-            for g, mx in ((2 * qb, a), (2 * qb + 1, b)):
-                y = lambda r: V(Sb + 16 * g + r)
-                blk += [I("v_max3_f32", mx, y(0), y(1), y(2))] + [I("v_max3_f32", mx, mx, y(2 * j + 1), y(2 * j + 2)) for j in range(1, 7)] + \
-                    [I("v_max_f32", mx, mx, y(15))]
-            blk += [I("v_max_f32", a, a, b), I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b), label(l_plain)]
-            return blk
+        p2 = 2 * (jd & 1)
+        l_d1, l_max = self.lab("fire_d1"), self.lab("fire_max")
         if cond is not None:
             blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_plain))]
-        blk += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc0", Label(l_plain))]
-        for g, mx in ((2 * qb, a), (2 * qb + 1, b)):
-            blk += self.score_mask_ops(Sb, g)
-            y = lambda r: V(Sb + 16 * g + r)
-            blk += [I("v_max3_f32", mx, y(0), y(1), y(2))] + [I("v_max3_f32", mx, mx, y(2 * j + 1), y(2 * j + 2)) for j in range(1, 7)] + \
-                [I("v_max_f32", mx, mx, y(15))]
-        blk += [I("v_max_f32", a, a, b), I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b), label(l_plain)]
-        return blk
+        blk += [I("s_cmp_eq_u32", S_WAVE, p2 + 1), I("s_cbranch_scc1", Label(l_d1)),
+                I("s_cmp_eq_u32", S_WAVE, p2), I("s_cbranch_scc0", Label(l_plain))]
+        blk += self.group_mask_ops(Sb, 2 * qb, "tri") + self.group_mask_ops(Sb, 2 * qb + 1, "all") + [I("s_branch", Label(l_max))]
+        blk += [label(l_d1)] + self.group_mask_ops(Sb, 2 * qb + 1, "tri") + [label(l_max)]
+        for q1 in range(2):
+            mx = V(V_MX[2 * qb + q1])
+            ys = [V(Sb + 16 * (2 * qb + kk) + 8 * q1 + r) for kk in range(2) for r in range(8)]
+            blk += [I("v_max3_f32", mx, ys[0], ys[1], ys[2])] + [I("v_max3_f32", mx, mx, ys[2 * j + 1], ys[2 * j + 2]) for j in range(1, 7)] + \
+                [I("v_max_f32", mx, mx, ys[15])]
+        return blk + [label(l_plain)]
 
     def mask_tests(self, Y, g, jd, cond=None):
         """causal: the tile whose softmax starts is diagonal tile jd (0..3) of its job: keys 64 jd .. 64 jd + 63 of the 256-key
@@ -983,7 +966,7 @@ class Gen:
         Returns the in-line tests for score group g (in front of its first row-maximum operation); the masking itself runs
         out of line.  The branch sits where that row-maximum operation is legal, i.e. the MFMA -> VALU wait states have passed
         (check.check_branch_targets verifies it on the built program)."""
-        if self.split:
+        if self.split:    # (always)
             # waves 2 p / 2 p + 1 (p = jd & 1) carry patterns D0 / D1 on query block jd >> 1 (see mask_lazy); a block wholly
             # hidden from a wave is not computed at all by the split bodies
             l_back = self.lab("mask_back")
@@ -1004,49 +987,61 @@ class Gen:
             l_tests = self.lab("mask_tests")
             self.ool.append([label(l_tests)] + tests + [I("s_branch", Label(l_back))])
             return [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_tests)), label(l_back)]
-        l_eq, l_lt, l_back = self.lab("mask_eq"), self.lab("mask_lt"), self.lab("mask_back")
-        tests = []
-        eq_ops = self.score_mask_ops(Y, g)
-        if eq_ops:
-            tests += [I("s_cmp_eq_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_eq))]
-            self.ool.append([label(l_eq)] + eq_ops + [I("s_branch", Label(l_back))])
-        if jd > 0:
-            tests += [I("s_cmp_lt_u32", S_WAVE, jd), I("s_cbranch_scc1", Label(l_lt))]
-            self.ool.append([label(l_lt)] + [I("v_mov_b32", V(Y + 16 * g + r), NINF) for r in range(16)] +
-                            [I("s_branch", Label(l_back))])
-        if cond is None:
-            return tests + [label(l_back)]
-        if not tests:
-            return []
-        # the tile is diagonal only in the loop's last trip (or for a one-tile-row job): the common path falls through one
-        # compare and one untaken branch -- a TAKEN branch over the tests cost ~25 cycles per step in the steady loop
-        l_tests = self.lab("mask_tests")
-        self.ool.append([label(l_tests)] + tests + [I("s_branch", Label(l_back))])
-        return [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc1", Label(l_tests)), label(l_back)]
+        raise AssertionError("the a16 kernels use the split row map only")
 
     # ------------------------------------------------------------------ the two phases
+    def emit_slot(self, m, entries, keep_order=False):
+        """one MFMA slot and the fillers behind it.  entries: [(order, [insts])] with order 0 = LDS / DMA loads, 1 = exp2, 2 = the
+        rest, 3 = last.  A slot of two MFMAs splits its fillers between the two half gaps (each MFMA holds the vector issue port
+        for 8 of its 16 cycles): in their order, cut where the issue costs of the halves balance"""
+        from .isa import issue_cost
+        cost = lambda ins: sum(issue_cost(x) for x in ins)
+        if keep_order:
+            # (fillers of several original gaps, merged: they may depend on each other -- the order stands, the split is by cost)
+            if isinstance(m, Inst):
+                return [m] + [x for _, ins in entries for x in ins]
+            total, acc, out, second = sum(cost(i) for _, i in entries), 0, [m[0]], False
+            for _, ins in entries:
+                if not second and 2 * acc >= total:
+                    out.append(m[1])
+                    second = True
+                out += ins
+                acc += cost(ins)
+            return out if second else out + [m[1]]
+        entries = sorted(entries, key=lambda x: x[0])      # (stable: entries of equal order keep the order they were added in --
+        # the scalar units of `early` depend on each other)
+        if isinstance(m, Inst):
+            return [m] + [x for _, ins in entries for x in ins]
+        # the order stands; the second MFMA goes where the two half gaps balance best (an LDS read costs the port about half of
+        # what a VALU instruction does; 'last' entries -- a DMA piece's scalar set-up -- stay behind the second MFMA)
+        w = [cost(ins) // 2 if o == 0 else cost(ins) for o, ins in entries]
+        n_mov = sum(1 for o, _ in entries if o != 3)
+        best, cut = None, 0
+        for k in range(n_mov + 1):
+            imb = abs(sum(w[:k]) - sum(w[k:]))
+            if best is None or imb < best:
+                best, cut = imb, k
+        out = [m[0]] + [x for _, ins in entries[:cut] for x in ins] + [m[1]] + [x for _, ins in entries[cut:] for x in ins]
+        return out
+
     def emit_phase(self, mfmas, gaps):
-        """gaps[k] = fillers behind MFMA k: (order, [insts]) with order 0 = LDS / DMA loads, 1 = exp2, 2 = the rest, 3 = last"""
+        """gaps[k] = fillers behind slot k: (order, [insts]); a slot is one MFMA or a pair (emit_slot)"""
         out = []
         kept = [k for k, m in enumerate(mfmas) if m is not None]
         if len(kept) == len(mfmas):
             for k, m in enumerate(mfmas):
-                out.append(m)
-                for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
-                    out += ins
+                out += self.emit_slot(m, gaps.get(k, []))
             return out
-        # some MFMAs are left out (a query block the tile is hidden from): the fillers of the original gaps, each gap's group
-        # kept whole and in the original order, are spread over the remaining MFMAs in proportion -- a filler never moves in
+        # some slots are left out (a query block the tile is hidden from): the fillers of the original gaps, each gap's group
+        # kept whole and in the original order, are spread over the remaining slots in proportion -- a filler never moves in
         # front of an MFMA it followed (check.fix pads what lands too close behind one)
         n, nk = len(mfmas), len(kept)
         assert nk > 0, "a phase without MFMAs is emitted by its caller"
         buckets = [[] for _ in range(nk)]
         for k in range(n):
-            for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
-                buckets[min(k * nk // n, nk - 1)] += ins
+            buckets[min(k * nk // n, nk - 1)] += sorted(gaps.get(k, []), key=lambda x: x[0])
         for idx, k in enumerate(kept):
-            out.append(mfmas[k])
-            out += buckets[idx]
+            out += self.emit_slot(mfmas[k], buckets[idx], keep_order=True)
         return out
 
     def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=(), cur_masks=None, extra=(),
@@ -1079,22 +1074,20 @@ class Gen:
         return self.emit_phase(mf, gaps)
 
     def pv_mfmas(self, X, qbs=(0, 1)):
-        """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep) with P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s; behind each
-        k-step the row sums of its two P fragments on the matrix pipe: a 16x16x32 MFMA against the 0 / 1 operand V_ONES puts
-        the 16-key sum of the lane's own query into register 0 of V_LACC[qb] (fa2_mfma16h.hip, FA2_H_MSUM, has the lane maths)"""
+        """O^T(qb16, db16) += V^T(kk, db16) . P^T(qb16, kk) as 32 slots of two MFMAs (the blocks of a query block qh share the V^T
+        fragment, and so do the two slots of a (kk, db16)); behind every eight slots the row sums of two P fragments on the matrix
+        pipe: against the all-ones operand V_ONES every row of D is the 32-key sum of the lane's own query (V_LACC[qb16])"""
         out = []
-        mfma16 = "v_mfma_f32_16x16x32_" + self.dtype
-        for kstep in range(4):
-            kb, s = kstep >> 1, kstep & 1
-            for db in range(4):
-                for qb in range(2):
-                    pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), pf, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}")
-                               if qb in qbs else None)
-            for qb in range(2):
-                pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                out.append(I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}")
-                           if qb in qbs and "no_rowsum" not in self.abl else None)   # (no_rowsum: timing-only, l stays 0)
+        for kk in range(2):
+            for half in range(2):
+                for db16 in range(4 * half, 4 * half + 4):
+                    for qh in range(2):
+                        pair = [I(self.mfma, A_O(q, db16), V_F(kk, db16), P_OP(X, q, kk), A_O(q, db16), tag=f"pv kk{kk} db{db16} qb{q}")
+                                for q in (2 * qh, 2 * qh + 1)]
+                        out.append(pair if qh in qbs else None)
+                for q in (2 * half, 2 * half + 1):
+                    out.append(I(self.mfma, V(V_LACC[q], 4), V(V_ONES, 4), P_OP(X, q, kk), V(V_LACC[q], 4), tag=f"rowsum kk{kk} qb{q}")
+                               if half in qbs and "no_rowsum" not in self.abl else None)   # (no_rowsum: timing-only, l stays 0)
         return out
 
     def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
@@ -1163,16 +1156,19 @@ class Gen:
             blk = [label(l_rs), I("s_nop", 15)]
             tmp = [V(V_T[k]) for k in range(8)]
             co = V(V_T[8], 2)      # (an even register: the factor is read as the low word of an aligned 64-bit operand)
-            for qb in range(2):
+            for qh in range(2):
                 l_skip = self.lab("rescale_skip")
-                blk += [I("s_bitcmp1_b32", S_FLAG, qb), I("s_cbranch_scc0", Label(l_skip)), I("v_mov_b32", co.sub(0), V(V_CO[qb]))]
-                for base in range(0, 64, 8):
-                    regs = [A(qb * 64 + base + k) for k in range(8)]
-                    blk += [I("v_accvgpr_read_b32", tmp[k], regs[k]) for k in range(8)]
-                    blk += [I("v_pk_mul_f32", V(tmp[k].idx, 2), V(tmp[k].idx, 2), co, op_sel_hi=(1, 0)) for k in range(0, 8, 2)]
-                    blk += [I("v_accvgpr_write_b32", regs[k], tmp[k]) for k in range(8)]
-                blk += [I("v_pk_mul_f32", V(V_LACC[qb] + k, 2), V(V_LACC[qb] + k, 2), co, op_sel_hi=(1, 0)) for k in (0, 2)]
-                blk += [I("v_mov_b32", V(V_CO[qb]), 1.0), label(l_skip)]
+                blk += [I("s_bitcmp1_b32", S_FLAG, qh), I("s_cbranch_scc0", Label(l_skip))]
+                for q in (2 * qh, 2 * qh + 1):
+                    blk += [I("v_mov_b32", co.sub(0), V(V_CO[q])), I("s_nop", 0)]
+                    for base in range(0, 32, 8):
+                        regs = [A(q * 32 + base + k) for k in range(8)]
+                        blk += [I("v_accvgpr_read_b32", tmp[k], regs[k]) for k in range(8)]
+                        blk += [I("v_pk_mul_f32", V(tmp[k].idx, 2), V(tmp[k].idx, 2), co, op_sel_hi=(1, 0)) for k in range(0, 8, 2)]
+                        blk += [I("v_accvgpr_write_b32", regs[k], tmp[k]) for k in range(8)]
+                    blk += [I("v_pk_mul_f32", V(V_LACC[q] + k, 2), V(V_LACC[q] + k, 2), co, op_sel_hi=(1, 0)) for k in (0, 2)]
+                    blk += [I("v_mov_b32", V(V_CO[q]), 1.0)]
+                blk += [label(l_skip)]
             blk += [I("s_mov_b32", S_FLAG, 0), I("s_nop", 3), I("s_branch", Label(l_back))]
             self.ool.append(blk)
         return body
@@ -1231,26 +1227,24 @@ class Gen:
         e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global; O^T := 0"))
         # (the O and L descriptors of this job were formed in the seam's last phase B: epilogue_descs)
         e(I("s_nop", 15))  # last P.V MFMAs -> accumulator reads
-        l = [t[0], t[3]]
-        m2 = [t[1], t[5]]
-        inv = [t[2], t[4]]    # (even registers: they are read as the low word of an aligned 64-bit operand below)
-        for qb in range(2):   # register 0 of the row-sum accumulator is the lane's own complete row sum (both lane halves)
-            e(I("v_mov_b32", l[qb], V(V_LACC[qb])))
-        for qb in range(2):
-            e(I("v_rcp_f32", inv[qb], l[qb]), I("v_log_f32", m2[qb], l[qb]))
+        inv = [t[0], t[2], t[4], t[6]]    # (even registers: they are read as the low word of an aligned 64-bit operand below)
+        m2 = [t[1], t[3], t[5], t[7]]
+        nt = [t[8], t[9]]
+        lsum = [V(V_LACC[q]) for q in range(4)]   # every register of a row-sum accumulator is the lane's own complete row sum
+        for q in range(4):
+            e(I("v_rcp_f32", inv[q], lsum[q]), I("v_log_f32", m2[q], lsum[q]))
         e(I("s_nop", 0))
-        for qb in range(2):
+        for q in range(4):
             # one Newton step: inv += inv * (1 - l * inv)
-            e(I("v_fma_f32", l[qb], -l[qb], inv[qb], 1.0), I("v_add_f32", m2[qb], m2[qb], V(V_MSV[qb])))
-        for qb in range(2):
-            e(I("v_fma_f32", inv[qb], l[qb], inv[qb], inv[qb]), I(self.cvt, m2[qb], m2[qb], m2[qb]))
+            e(I("v_fma_f32", nt[q & 1], -lsum[q], inv[q], 1.0), I("v_add_f32", m2[q], m2[q], V(V_MSV[q])))
+            e(I("v_fma_f32", inv[q], nt[q & 1], inv[q], inv[q]), I(self.cvt, m2[q], m2[q], m2[q]))
+        e(self.k_epi_consts())      # (the row sums are consumed: their registers hold the epilogue's lane constants from here on)
         e(self.stamp_async(0))
-        self.atmp_regs = (V_T[0], V_T[3])     # (the row sums are consumed: V_T[6..9] are LDS addresses from here on)
-        # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row i, chunk 4 db + g4, +8 h); one query block at a time.
-        # (S[0] already holds the next job's first scores and v[128:191] its K(1): rows and temporaries are score buffer 1,
-        # whose P was consumed by the job's last P.V.)  A batch = the four 8-byte groups of one 32-column block; the stages
-        # of consecutive batches (accumulator reads | scale | pack, address | LDS write) are woven so that no instruction
-        # waits on its predecessor.
+        # O: 4 accumulators (four consecutive columns of one query) -> 2 packed registers -> ds_write_b64 at (row li + 16 q', byte
+        # 32 db16 + 8 g); one query block (32 rows) at a time.  (S[0] already holds the next job's first scores and v[128:191]
+        # its K(1): rows and temporaries are score buffer 1, whose P was consumed by the job's last P.V.)  A batch = four 16-column
+        # blocks of one 16-row block; the stages of consecutive batches (accumulator reads | scale | pack | LDS write) are woven so
+        # that no instruction waits on its predecessor.
         rows = [V(SBUF[1] + 4 * k, 4) for k in range(8)]
         tset = [[V(SBUF[1] + 32 + 16 * sidx + k) for k in range(16)] for sidx in range(2)]
 
@@ -1273,11 +1267,11 @@ class Gen:
                     out += extras[j]
             return out
 
-        def row_stores(qb, off=S_T[0], stride=S_T[1], restride=False):
-            """[[instructions of one row store]] of query block qb (its rows are back in `rows`).  restride: the 4-row stride is
+        def row_stores(qh, off=S_T[0], stride=S_T[1], restride=False):
+            """[[instructions of one row store]] of query block qh (its rows are back in `rows`).  restride: the 4-row stride is
             formed again in front of every store (scalar code that uses `stride` runs between the stores)"""
             pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, off)
-            out = [[I("s_mul_i32", off, S_QROW[qb], S_OSN), I("s_lshl_b32", stride, S_OSN, 2)] + pre + [st]]
+            out = [[I("s_mul_i32", off, S_QROW[qh], S_OSN), I("s_lshl_b32", stride, S_OSN, 2)] + pre + [st]]
             for k in range(1, 8):
                 pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, off)
                 out.append(([I("s_lshl_b32", stride, S_OSN, 2)] if restride else []) + [I("s_add_u32", off, off, stride)] + pre + [st])
@@ -1289,26 +1283,28 @@ class Gen:
                 out.append(I("ds_read_b128", rows[k], V(V_ER), offset=4 * EPI_ROW * k))
             return out
 
-        for qb in range(2):
-            stages = []  # per batch: [reads, muls + address, packs, writes]
-            for db in range(4):
-                tm = tset[db & 1]
-                src = A_O(qb, db)
+        for qh in range(2):
+            stages = []  # per batch: [reads, muls, packs, writes]
+            for bi in range(4):
+                q1, c = bi >> 1, bi & 1
+                q = 2 * qh + q1
+                tm = tset[bi & 1]
+                src = A(32 * q + 16 * c, 16)       # O^T(q, db16 = 4 c .. 4 c + 3)
                 rd = [I("v_accvgpr_read_b32", tm[k], src.sub(k)) for k in range(16)]
                 # (packed fp32 multiplies: half the instructions; beside an MFMA they would cost ~50 cycles each, here the
                 # matrix pipe is idle and every VALU instruction takes the same ~5.8 cycles at one wave per SIMD)
-                mu = [I("v_pk_mul_f32", V(tm[k].idx, 2), V(tm[k].idx, 2), V(inv[qb].idx, 2), op_sel_hi=(1, 0)) for k in range(0, 16, 2)]
+                mu = [I("v_pk_mul_f32", V(tm[k].idx, 2), V(tm[k].idx, 2), V(inv[q].idx, 2), op_sel_hi=(1, 0)) for k in range(0, 16, 2)]
                 cv = []
-                for g4 in range(4):
-                    cv += [I(self.cvt, tm[4 * g4], tm[4 * g4], tm[4 * g4 + 1]), I(self.cvt, tm[4 * g4 + 1], tm[4 * g4 + 2], tm[4 * g4 + 3])]
-                wr = [I("ds_write_b64", V(V_EW), V(tm[4 * g4].idx, 2), offset=16 * (4 * db + g4)) for g4 in range(4)]
+                for k4 in range(4):
+                    cv += [I(self.cvt, tm[4 * k4], tm[4 * k4], tm[4 * k4 + 1]), I(self.cvt, tm[4 * k4 + 1], tm[4 * k4 + 2], tm[4 * k4 + 3])]
+                wr = [I("ds_write_b64", V(V_EW), V(tm[4 * k4].idx, 2), offset=16 * EPI_ROW * q1 + 32 * (4 * c + k4)) for k4 in range(4)]
                 stages.append((rd, mu, cv, wr))
             # software pipeline over the four batches (two register sets): batch b + 1 is read while batch b is scaled, ...
             head = stages[0][0] + weave(stages[0][1], stages[1][0]) + stages[0][2] + stages[0][3]
             tail = weave(stages[1][1], stages[2][0]) + stages[1][2] + stages[1][3] + weave(stages[2][1], stages[3][0]) + \
                 stages[2][2] + stages[2][3] + stages[3][1] + stages[3][2] + stages[3][3]
             e(head)
-            if qb == 1:
+            if qh == 1:
                 e(self.stamp_async(2))
                 # the first block's rows have been on their way back from LDS since before this block started (four of this
                 # block's writes are younger): wait for them once, then one row store every ~25 instructions
@@ -1317,25 +1313,26 @@ class Gen:
             else:
                 e(tail)
             e(read_back())
-            e(self.stamp_async(1 if qb == 0 else 3))
-        # O^T := 0 and row sums := 0 for the next job; O on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
+            e(self.stamp_async(1 if qh == 0 else 3))
+        # O^T := 0 for the next job on the matrix pipe: eight 32x32x16 MFMAs on zero operands clear 16 accumulators each (instead
+        # of 128 v_accvgpr_write)
         z = V(SBUF[1] + 32, 4)    # (the second block's temporaries: free again)
-        e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
         e([I("v_mov_b32", z.sub(k), 0) for k in range(4)], I("s_nop", 1))
         # (the wave can issue one of these every 32 cycles and one row store every ~75 with all four waves storing: interleaved,
         # the stores hide the MFMAs; two MFMAs go first, under the read-back's LDS round trip)
-        zero = [I(self.mfma, A_O(qb, db), z, z, 0) for qb in range(2) for db in range(4)]
+        zero = [I("v_mfma_f32_32x32x16_" + self.dtype, A(16 * k, 16), z, z, 0) for k in range(8)]
         # (offset / stride registers the job bookkeeping below leaves alone: k_promote and k_advance use S_T[0..4], [6], [7])
         st1 = row_stores(1, off=S_T[5], stride=S_T[6], restride=True)
         e(zero[0], zero[1])
         e(self.stamp_async(4))
         e(waitcnt(lgkmcnt=0))
         e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the scalar code below: it uses the stamp registers)
-        # L store (lanes 0..31), in the I/O dtype: in front of the job bookkeeping (it needs this job's row numbers and S_T)
-        e(I("s_lshr_b64", EXEC, EXEC, 32))
-        for qb in range(2):
-            pre, st = self.buf_op("buffer_store_short", m2[qb], V(V_L2), S_NVRS, S_T[0])
-            e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), pre, st)
+        # L store (lanes 0..15: the lanes of group g = 0 hold the sixteen rows of a block), in the I/O dtype: in front of the job
+        # bookkeeping (it needs this job's row numbers and S_T)
+        e(I("s_mov_b64", EXEC, 0xFFFF))
+        for q in range(4):
+            pre, st = self.buf_op("buffer_store_short", m2[q], V(V_L2), S_NVRS, S_T[0])
+            e(I("s_add_u32", S_T[0], S_QROW[q >> 1], 16 * (q & 1)), I("s_lshl_b32", S_T[0], S_T[0], 1), pre, st)
         e(I("s_mov_b64", EXEC, -1))
         for k in range(8):
             e(st1[k])
@@ -1351,7 +1348,8 @@ class Gen:
                 self.k_promote()
                 self.k_advance(vt=(tset[0][4], tset[0][5]))     # (not z: SBUF[1] + 32..35 is the zero MFMAs' operand)
                 e(label(l_last))
-        self.atmp_regs = (V_T[8], V_T[9])
+        # the row sums of the next job start from zero (their registers held the epilogue's lane constants until the last store)
+        e([I("v_mov_b32", V(V_LACC[q] + k), 0) for q in (1, 2, 3, 0) for k in range(4)])
 
     # ------------------------------------------------------------------ the whole kernel
     def build(self):
@@ -1429,7 +1427,7 @@ class Gen:
                     early += self.epilogue_descs()
                     # the job's last tile: its running maxima are put aside for the epilogue before the next job's first
                     # tile re-initialises them (its row sums stay in V_LACC until the epilogue has read them)
-                    save = [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])) for qb in range(2)]
+                    save = [I("v_mov_b32", V(V_MSV[q]), V(V_MC[q])) for q in range(4)]
                     if (cm and not self.split) or (self.ragged and not cm):   # (behind the tile's 'mr': until then V_MSV holds what 'ms' put aside, mask_lazy)
                         kw.update(nxt_init=True, extra=list(kw.get("extra", ())) + [(self.LAZY_TAU["mr"] - self.PERIOD + 1, save)])
                     else:
@@ -1542,94 +1540,12 @@ class Gen:
             f"    .wavefront_size: 64"])
 
 
-ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
-             "nodma": ("nodma",), "nokread": ("nokread",), "nostart": ("nostart",), "nofinish": ("nofinish",),
-             "novread": ("novread",), "mfmaonly": ("nodma", "nokread", "nostart", "nofinish", "novread"),
-             "nomx": ("no_mx",), "nodec": ("no_dec",), "nofire": ("no_fire",), "nof": ("no_f",), "noe": ("no_e",), "nocv": ("no_cv",),
-             "nofecv": ("no_f", "no_e", "no_cv"), "nolds": ("nokread", "novread", "nodma"),
-             "nobar_nostart": ("nobarrier", "nostart"), "nobar_nolds": ("nobarrier", "nokread", "novread", "nodma"),
-             "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire"),
-             "fire_nobranch": ("fire_nobranch",)}
-
-
-# named variants of the experiments build (make experiments; FA2_A64_KERNEL=fa2_fwd_a64_bf16_<c|n>_<tag> selects one per launch:
-# benchmarks/variants.py interleaves them in one process, which resolves +-0.3 % -- across gpurun calls boxes differ by 7 %).
-# Measured that way on c3 causal: nolean -1.0 %; plan capacities (6, 26) / (6, 24) / (5, 26) / (5, 25) +-0.3 %, (7, 28) -1.7 %;
-# one-chain-after-the-other QK^T order -0.2 %; zero-operand K and V^T fragments for hidden tiles +0.4 % / 0 (dropped for the
-# lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
-# lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
-# issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)),
-            "norowsum": dict(abl=("no_rowsum",))}     # (norowsum: timing-only bound of what the row-sum MFMAs cost; outputs are wrong)
-
-
-def module_text(gens):
-    head = ['.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', ".amdhsa_code_object_version 6", ".text", ""]
-    body = "\n".join(head) + "\n".join(g.text() for g in gens)
-    md = ["", ".amdgpu_metadata", "---", "amdhsa.kernels:"] + [g.metadata() for g in gens] + [
-        "amdhsa.target: amdgcn-amd-amdhsa--gfx950", "amdhsa.version:", "  - 1", "  - 2", "...", ".end_amdgpu_metadata", ""]
-    return body + "\n".join(md)
-
-
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-o", "--output", required=True)
-    ap.add_argument("--stamps", action="store_true", help="diagnostic build: job-timeline stamps into the debug buffer")
-    ap.add_argument("--variants", action="store_true", help="experiments build: the product kernels plus named variants (A/B in one process)")
-    args = ap.parse_args(argv)
-    from .check import check
-    gens = []
-    for dtype, causal, ragged in [(dt, c, False) for dt in ("bf16", "f16") for c in (False, True)] + \
-            ([] if args.stamps else [(dt, c, True) for dt in ("bf16", "f16") for c in (False, True)]):
-        if True:
-            g = Gen(dtype, causal, stamps=args.stamps, ragged=ragged)
+def product_gens():
+    """the kernels of this generator that ship in libfa2_hip.so's code object (built by fa2_a64_gen.main)"""
+    out = []
+    for dtype in ("bf16", "f16"):
+        for causal, ragged in ((False, False), (True, False)):
+            g = Gen(dtype, causal, ragged=ragged)
             g.build()
-            errs = check(g.prog)
-            if errs:
-                print(f"{g.name}: {len(errs)} wait-state violations", file=sys.stderr)
-                return 1
-            gens.append(g)
-    if not args.stamps:   # the same structure on v_mfma_f32_16x16x32 (fa2_a16_gen.py): same code object, same argument block
-        from .fa2_a16_gen import product_gens
-        for g in product_gens():
-            errs = check(g.prog)
-            if errs:
-                print(f"{g.name}: {len(errs)} wait-state violations", file=sys.stderr)
-                return 1
-            gens.append(g)
-    if args.stamps:  # timing-only ablations ride in the diagnostic code object
-        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite", stamps=True, abl=("lite",))
-        g.build()
-        gens.append(g)
-        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_nosplit", stamps=True, abl=("lite",), split=False)
-        g.build()
-        gens.append(g)
-        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_noqreads", stamps=True, abl=("lite", "noqreads"))
-        g.build()
-        gens.append(g)
-        for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
-            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
-            g.build()
-            gens.append(g)
-    if args.stamps:     # ... and of the 16x16x32 form (non-causal: its stamp registers are the causal kernels' mask registers)
-        from .fa2_a16_gen import Gen as Gen16
-        for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
-            g = Gen16("bf16", False, name=f"fa2_fwd_a16_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
-            g.build()
-            gens.append(g)
-        g = Gen16("bf16", True, name="fa2_fwd_a16_bf16_c_lite", stamps=True, abl=("lite",))
-        g.build()
-        gens.append(g)
-    if args.variants:   # selected at run time through FA2_A64_KERNEL in the experiments library (benchmarks/variants.py)
-        for tag, kw in VARIANTS.items():
-            for causal in (False, True):
-                g = Gen("bf16", causal, name=f"fa2_fwd_a64_bf16_{'c' if causal else 'n'}_{tag}", **kw)
-                g.build()
-                gens.append(g)
-    with open(args.output, "w") as f:
-        f.write(module_text(gens))
-    return 0
-
-
-if __name__ == "__main__":
-    sys.exit(main())
+            out.append(g)
+    return out

@@ -207,7 +207,7 @@ class Inst:
             return [], R(o[0]) + R(o[1]) + R(o[2]) + R(o[3])
         if op.startswith("global_store"):
             return [], R(o[0]) + R(o[1]) + (R(o[2]) if len(o) > 2 else [])
-        if op == "v_permlane32_swap_b32":
+        if op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32"):
             return R(o[0]) + R(o[1]), R(o[0]) + R(o[1])
         if op.startswith("v_cmp_"):
             return R(o[0]), R(o[1]) + R(o[2])

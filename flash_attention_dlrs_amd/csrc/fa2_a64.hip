@@ -39,7 +39,7 @@ constexpr int kMaxDev = 64;
 struct DevState {
     bool ready = false, failed = false;
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2][2][2] = {};  // [bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
+    hipFunction_t fn[2][2][2][2] = {};  // [a64 / a16][bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
     int cus = 0;
 };
 DevState g_dev[kMaxDev];
@@ -70,15 +70,15 @@ DevState *dev_state() {
         fa2_set_error("a64: hipModuleLoadData failed: %s", hipGetErrorString(e));
         return nullptr;
     }
-    static const char *names[2][2] = {{"fa2_fwd_a64_bf16_n", "fa2_fwd_a64_bf16_c"}, {"fa2_fwd_a64_f16_n", "fa2_fwd_a64_f16_c"}};
-    for (int t = 0; t < 2; ++t)
-        for (int c = 0; c < 2; ++c)
-            for (int r = 0; r < 2; ++r) {
-                char nm[64];
-                snprintf(nm, sizeof(nm), "%s%s", names[t][c], r ? "r" : "");
-                e = hipModuleGetFunction(&d.fn[t][c][r], d.mod, nm);
-                if (e != hipSuccess) d.fn[t][c][r] = nullptr;  // a kernel the generator did not emit: reported at launch
-            }
+    for (int m = 0; m < 2; ++m)
+        for (int t = 0; t < 2; ++t)
+            for (int c = 0; c < 2; ++c)
+                for (int r = 0; r < 2; ++r) {
+                    char nm[64];
+                    snprintf(nm, sizeof(nm), "fa2_fwd_%s_%s_%s%s", m ? "a16" : "a64", t ? "f16" : "bf16", c ? "c" : "n", r ? "r" : "");
+                    e = hipModuleGetFunction(&d.fn[m][t][c][r], d.mod, nm);
+                    if (e != hipSuccess) d.fn[m][t][c][r] = nullptr;  // a kernel the generator did not emit: reported at launch
+                }
     (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
     d.cus = fa2_device_cus();
     d.ready = true;
@@ -105,7 +105,17 @@ bool fa2_a64_supports(const Fa2Problem &p) {
     return true;
 }
 
-int fa2_launch_a64(const Fa2Problem &p) {
+namespace {
+int launch(const Fa2Problem &p, int shape16);
+}
+
+// The a16 kernels take what the a64 kernels take (same argument block, same job stream).
+bool fa2_a16_supports(const Fa2Problem &p) { return fa2_a64_supports(p); }
+int fa2_launch_a64(const Fa2Problem &p) { return launch(p, 0); }
+int fa2_launch_a16(const Fa2Problem &p) { return launch(p, 1); }
+
+namespace {
+int launch(const Fa2Problem &p, int shape16) {
     if (!fa2_a64_supports(p)) {
         fa2_set_error("a64 kernel: needs f16/bf16, d = 128, N >= 256, unit d-stride, 16-byte aligned rows, "
                       "scale > 0, N * row stride < 2 GiB");
@@ -113,9 +123,9 @@ int fa2_launch_a64(const Fa2Problem &p) {
     }
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
-    hipFunction_t fn = d->fn[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
+    hipFunction_t fn = d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {
-        fa2_set_error("a64 kernel: this (dtype, causal) form is not in the code object");
+        fa2_set_error("%s kernel: this (dtype, causal, ragged N) form is not in the code object", shape16 ? "a16" : "a64");
         return FA2_ERR_UNSUPPORTED;
     }
     A64Args a;
@@ -195,3 +205,4 @@ int fa2_launch_a64(const Fa2Problem &p) {
     }
     return FA2_OK;
 }
+}  // namespace

@@ -76,7 +76,16 @@ int pick_variant(const Fa2Problem &p) {
         // MFMA16D_W4 / MFMA16H / MFMA16K it is 4-33 % faster on every shape from those sizes up (the persistent grid also
         // takes job counts that are not a multiple of the CU count better: 1.5 jobs per CU 180 vs 213 us); on the same
         // MI355X against MFMA16H: c3 causal +15-19 %, c3 shape non-causal +15-17 %.
-        if (fa2_a64_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) return FA2_VARIANT_A64;
+        if (fa2_a64_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) {
+            // The same kernel on the other matrix shape (A16: v_mfma_f32_16x16x32, asm/fa2_a16_gen.py): 15 % more cycles per key
+            // step, but the chip holds a 10-17 % higher clock under it.  Same-device A/B against A64 (benchmarks/variants.py,
+            // profiles/r03/a16_vs_a64.jsonl), bf16: non-causal N = 4096 +2.4 .. +4.4 %, N = 8192 (BASELINE configs[3]'s shard)
+            // +4.4 %, N = 2048 +1.3 %; causal N = 8192 +2.0 %, N = 4096 -1.0 %, N = 2048 -3.5 % (short jobs: the seam and the
+            // epilogue grow with the cycles, the clock gain is smaller there); f16 (rescales every few tiles) -2.5 %.
+            // It has no ragged form yet.
+            if (p.dtype == FA2_DTYPE_BF16 && (p.N & 255) == 0 && (p.causal ? p.N >= 8192 : p.N >= 4096)) return FA2_VARIANT_A16;
+            return FA2_VARIANT_A64;
+        }
         // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and
         // every workgroup walks its key tiles in sequence -- latency-bound.  MFMA16K splits the keys of a tile among
         // wave groups of the same workgroup (no workspace): benchmarks/tiny_grid.py, HIP-graph replay, fp16:
@@ -163,6 +172,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16H: return fa2_launch_mfma16h(p, 8);
     case FA2_VARIANT_MFMA16H_W4: return fa2_launch_mfma16h(p, 4);
     case FA2_VARIANT_A64: return fa2_launch_a64(p);
+    case FA2_VARIANT_A16: return fa2_launch_a16(p);
 #ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
     case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
@@ -304,6 +314,7 @@ int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_
     case FA2_VARIANT_MFMA16X: out4[1] = 256; out4[2] = 32; out4[3] = 4; break;
 #endif
     case FA2_VARIANT_A64: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
+    case FA2_VARIANT_A16: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
 #ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;

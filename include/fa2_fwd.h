@@ -68,6 +68,8 @@ extern "C" {
                            /* Non-finite inputs: as the reference, except that a NaN in query row q also makes row q ^ 16 of   */
                            /* the same 32-row block NaN (the row sums run on the matrix pipe, where q ^ 16's P meets a zero    */
                            /* weight); finite inputs are unaffected.                                                          */
+#define FA2_VARIANT_A16 25 /* the A64 structure on the other matrix shape, v_mfma_f32_16x16x32 (the chip holds a higher clock on it):  */
+                           /* same shapes, same job stream; a 64-key step is 136 MFMAs of 16 cycles instead of 72 of 32.          */
 /* (ids 5-7, 10-13, 18 and the ablation ids belong to experimental kernels that are not part of this library:
  *  flash_attention_dlrs_amd/csrc/fa2_experiments.h, `make -C flash_attention_dlrs_amd/csrc experiments`) */
 

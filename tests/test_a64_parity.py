@@ -52,37 +52,46 @@ def check(O, L, O_ref, L_ref, dtype):
 
 
 SHAPES = [(1, 1, 256), (2, 3, 512), (1, 2, 768), (1, 5, 1024)]
+# the generated kernel in its two matrix shapes: "a64" on v_mfma_f32_32x32x16, "a16" on v_mfma_f32_16x16x32 (same structure, same
+# arithmetic order: the tests below hold for both)
+GEN_VARIANTS = ["a64", "a16"]
+both = pytest.mark.parametrize("variant", GEN_VARIANTS)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_seeded_vs_oracle(oracle, dtype, causal, shape):
+@both
+def test_seeded_vs_oracle(oracle, dtype, causal, shape, variant):
     B, H, N = shape
     Q, K, V = rand3((B, H, N, 128), dtype, seed=N + H)
-    check(*a64(Q, K, V, causal), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
+    check(*a64(Q, K, V, causal, variant=variant), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
 
 
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 128 ** -0.5), (torch.float16, 0.25)])
-def test_scale_and_default_table(oracle, dtype, scale):
+@both
+def test_scale_and_default_table(oracle, dtype, scale, variant):
     Q, K, V = rand3((1, 2, 512, 128), dtype, seed=5)
     O_ref, L_ref = oracle_fwd(oracle, Q, K, V, dtype, True, scale)
-    check(*a64(Q, K, V, True, scale), O_ref, L_ref, dtype)
+    check(*a64(Q, K, V, True, scale, variant=variant), O_ref, L_ref, dtype)
 
 
 def test_default_table_picks_a64_for_the_north_star_shape():
     assert _lib.query_tile(4096, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64
-    assert _lib.query_tile(8192, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
+    assert _lib.query_tile(8192, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16   # long non-causal bf16: the 16x16x32 form
+    assert _lib.query_tile(8192, 128, _lib.FA2_DTYPE_F16, False)[0] == _lib.VARIANT_A64
+    assert _lib.query_tile(8192, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A16 and _lib.query_tile(4096, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16
     assert _lib.query_tile(4000, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64   # N not a multiple of 256: the ragged kernels
     assert _lib.query_tile(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64    # d = 64
 
 
-def test_many_jobs_per_workgroup_and_job_order(oracle):
+@both
+def test_many_jobs_per_workgroup_and_job_order(oracle, variant):
     """more jobs than CUs: every workgroup walks several jobs (seam: next-job prefetch, epilogue between jobs), causal pairs"""
     dtype = torch.bfloat16
     Q, K, V = rand3((3, 48, 512, 128), dtype, seed=9)      # 288 (b, h) x 2 query blocks = 576 jobs, B * H not a power of two
     for causal in (False, True):
-        O, L = a64(Q, K, V, causal)
+        O, L = a64(Q, K, V, causal, variant=variant)
         # the oracle on a few heads (it takes seconds per head at this size), all heads against each other through SDPA
         for (b, h) in ((0, 0), (1, 17), (2, 47)):
             O_ref, L_ref = oracle_fwd(oracle, Q[b:b + 1, h:h + 1], K[b:b + 1, h:h + 1], V[b:b + 1, h:h + 1], dtype, causal)
@@ -92,35 +101,38 @@ def test_many_jobs_per_workgroup_and_job_order(oracle):
         assert (O.float() - ref).abs().max() <= O_TOL[dtype]
 
 
-def test_many_jobs_f16_rescale_across_job_seams():
+@both
+def test_many_jobs_f16_rescale_across_job_seams(variant):
     """f16 defers the running maximum by at most 15.875 log2 units, so O and l are rescaled often: with several jobs per workgroup
     every rare path (firing, deferred rescale, epilogue, next job's prefetch) meets every other"""
     dtype = torch.float16
     Q, K, V = rand3((2, 160, 512, 128), dtype, seed=13)      # 640 jobs on 256 workgroups
     for causal in (False, True):
-        O, _ = a64(Q, K, V, causal)
+        O, _ = a64(Q, K, V, causal, variant=variant)
         ref = torch.nn.functional.scaled_dot_product_attention(Q.to(DEV).float(), K.to(DEV).float(), V.to(DEV).float(),
                                                                scale=1.0, is_causal=causal).cpu()
         assert torch.isfinite(O.float()).all()
         assert (O.float() - ref).abs().max() <= O_TOL[dtype]
 
 
-def test_strided_inputs(oracle):
+@both
+def test_strided_inputs(oracle, variant):
     """(B, N, H, d) storage viewed as (B, H, N, d) (row stride H * d), and rows padded to 136 elements"""
     dtype = torch.bfloat16
     gen = torch.Generator().manual_seed(21)
     Q, K, V = (torch.randn(2, 512, 3, 128, generator=gen).to(dtype).transpose(1, 2) for _ in range(3))
     assert not Q.is_contiguous()
-    check(*a64(Q, K, V, True), *oracle_fwd(oracle, Q, K, V, dtype, True), dtype)
+    check(*a64(Q, K, V, True, variant=variant), *oracle_fwd(oracle, Q, K, V, dtype, True), dtype)
     Qp, Kp, Vp = (torch.randn(1, 2, 256, 136, generator=gen).to(dtype)[..., :128] for _ in range(3))
     assert Qp.stride(2) == 136
-    O, L = fa.flash_attention_forward(Qp.to(DEV), Kp.to(DEV), Vp.to(DEV), DEV, variant="a64")
+    O, L = fa.flash_attention_forward(Qp.to(DEV), Kp.to(DEV), Vp.to(DEV), DEV, variant=variant)
     check(O.cpu(), L.cpu(), *oracle_fwd(oracle, Qp, Kp, Vp, dtype, False), dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("causal", [False, True])
-def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype, causal):
+@both
+def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype, causal, variant):
     """the kernel's liberties are exactly the ones oracle.forward_deferred states (running maximum kept per 32-row query block
     while no row of it exceeds m by 60 / 15.875 log2 units, exp2(fma), row sums of the rounded P): against THAT restatement the
     result is compared element by element -- at least 99 % of O bit-identical; an element that differs is off by its own
@@ -130,7 +142,7 @@ def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype,
     B, H, N = 1, 2, 512
     Q, K, V = rand3((B, H, N, 128), dtype, seed=77)
     K[:, :, 300] = (Q[:, :, 200].float() * 0.45).to(dtype)     # one row's maximum jumps past the f16 threshold mid-way
-    O, L = a64(Q, K, V, causal)
+    O, L = a64(Q, K, V, causal, variant=variant)
     f = lambda t: t.float().numpy()
     O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
                                            thr=60.0 if dtype == torch.bfloat16 else 15.875, sum_rounded=True)
@@ -146,7 +158,8 @@ def test_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype,
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_rescale_branch_is_exercised(oracle, dtype):
+@both
+def test_rescale_branch_is_exercised(oracle, dtype, variant):
     """the running maximum of one row jumps far beyond the deferral threshold (60 / 15.875 log2 units) in the last tiles, after O
     and l are non-zero: O *= coeff, l *= coeff are taken (cdna_hip_programming.md rule 26)"""
     B, H, N = 1, 2, 1024
@@ -156,10 +169,10 @@ def test_rescale_branch_is_exercised(oracle, dtype):
     K[:, :, 300] = Q[:, :, 200] * 6.0
     Q, K, V = (t.to(dtype) for t in (Q, K, V))
     for causal in (False, True):
-        check(*a64(Q, K, V, causal), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
+        check(*a64(Q, K, V, causal, variant=variant), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
 
 
-@pytest.mark.parametrize("variant", ["a64", "mfma16h", "mfma16"])
+@pytest.mark.parametrize("variant", ["a64", "a16", "mfma16h", "mfma16"])
 def test_tensors_that_straddle_a_4_gib_address_boundary(variant):
     """every 64-bit address the kernels form (descriptor base + b * stride_b + h * stride_h) must carry out of its low word:
     Q, K, V, O and L are placed so that each crosses a 4-GiB-aligned device address inside its own arena.  (The a64 seam once
@@ -193,7 +206,7 @@ def test_tensors_that_straddle_a_4_gib_address_boundary(variant):
     del keep
 
 
-@pytest.mark.parametrize("variant", ["a64", "mfma16h", "mfma16d_w4"])
+@pytest.mark.parametrize("variant", ["a64", "a16", "mfma16h", "mfma16d_w4"])
 def test_nan_and_inf_inputs_propagate_like_the_oracle(oracle, variant):
     """A NaN in Q poisons its row, a NaN in V its column of the rows that see it, a NaN key every row that sees it; +Inf in V
     gives +Inf / NaN as the oracle says.  (The default kernels are built with -fno-honor-nans: this pins the behaviour.)"""
@@ -321,7 +334,7 @@ def test_c4_per_gpu_shard_properties():
     dtype, B, H, N = torch.bfloat16, 8, 8, 8192
     torch.manual_seed(42)
     Q, K, V = (torch.randn(B, H, N, 128, device=DEV).to(dtype) for _ in range(3))
-    assert _lib.query_tile(N, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
+    assert _lib.query_tile(N, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16    # (the generated kernel in its 16x16x32 form)
     O, L = fa.flash_attention_forward(Q, K, V, DEV)
     O2, L2 = fa.flash_attention_forward(Q, K, V, DEV)
     assert torch.equal(O, O2) and torch.equal(L, L2)                                   # run-to-run bit equality

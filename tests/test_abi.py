@@ -120,7 +120,8 @@ def test_static_tile_table():
     q = _lib.query_tile
     # north-star config c3 and friends take the MFMA paths; odd head sizes and exotic dtypes fall back
     assert q(4096, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64          # north-star shape (c3): the assembly kernel
-    assert q(4096, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
+    assert q(4096, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16         # long non-causal bf16: the same kernel on 16x16x32
+    assert q(2048, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
     assert q(4096 + 64, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64      # (N not a multiple of 256: its ragged form)
     assert q(200, 128, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64            # below one 256-row job
     assert q(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_MFMA16H
