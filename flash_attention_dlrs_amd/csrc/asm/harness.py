@@ -25,7 +25,7 @@ def from_dt(u16, dtype):
     return u16.view(np.float16).astype(np.float32)
 
 
-def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, nbh, nwg, dbg=0, pow2=True):
+def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, nbh, nwg, dbg=0, pow2=True, pairs=False):
     """ptrs: Q,K,V,O,L addresses; strides_bh: (qs_b, qs_h, ks_b, ks_h, vs_b, vs_h, os_b, os_h, ls_b, ls_h) in bytes;
     strides_n: (qs_n, ks_n, vs_n, os_n) in bytes -- the layout of fa2_a64_gen.k_setup"""
     b = struct.pack("<5Q", *ptrs) + struct.pack("<10q", *strides_bh) + struct.pack("<4i", *strides_n)
@@ -35,12 +35,14 @@ def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, n
     ispow2 = lambda x: x > 0 and (x & (x - 1)) == 0
     if pow2 and nbh % 8 == 0 and ispow2(H) and ispow2(G) and ispow2(G * nunit):
         lg = (H.bit_length() - 1) | ((G.bit_length() - 1) << 8) | (((G * nunit).bit_length() - 1) << 16) | (1 << 24)
+    if pairs:      # causal head pairs (fa2_a64.hip: B * H a multiple of 16)
+        lg |= 1 << 25
     b += struct.pack("<II", lg, 0)
     assert len(b) == KARG_SIZE, len(b)
     return b
 
 
-def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1, pow2=True, thr_override=None):
+def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1, pow2=True, thr_override=None, pairs=False):
     """Q, K, V: float32 arrays (B, H, N, 128), rounded to dtype here.  Returns O (B,H,N,128) f32, L (B,H,N) f32."""
     B, H, N, D = Q.shape
     assert D == 128
@@ -57,13 +59,16 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     nunit = (nq + 1) // 2 if causal else nq
     nbh = B * H
     total = nunit * nbh
+    if pairs:      # a unit = (head A, query block nq - 1 - u) then (head B, query block u, walked downwards): fa2_a64_gen.Gen.pairs
+        assert causal and nbh % 16 == 0 and G == 1
+        nunit, total = nq, nq * nbh // 2
     nwg = nwg or min(total, 256)
     sb, sh, sn = H * N * D * 2, N * D * 2, D * 2
     thr = A64_THR[dtype]
     if thr_override is not None:
         thr = thr_override
     ka = pack_kargs([bufs[k][0] for k in "QKVOL"], (sb, sh) * 4 + (H * N * 2, N * 2), (sn,) * 4, N, H, nq, total,
-                    float(scale * LOG2E), thr, nunit, G, nbh, nwg, pow2=pow2)
+                    float(scale * LOG2E), thr, nunit, G, nbh, nwg, pow2=pow2, pairs=pairs)
     ka_arr = np.frombuffer(ka, np.uint8).copy()
     ka_addr = mem.alloc(ka_arr)
     steps = 0

@@ -72,6 +72,13 @@ def test_emulated_kernel_job_stream_and_wave_order(oracle):
     _run(oracle, "bf16", True, 1, 3, 256, nwg=1, order=[2, 0, 3, 1], seed=1)
 
 
+def test_emulated_causal_head_pairs(oracle):
+    """causal head pairs (Gen.pairs; the host sets bit 25 of the decode word when B * H is a multiple of 16): a unit is job (head A,
+    query block nq - 1 - u) then job (head B, query block u) whose non-diagonal key tiles are walked DOWNWARDS; eight workgroups
+    walk two units each (decode of both passes, stream start / step, the jump to the diagonal span in the steady loop's last trip)"""
+    _run(oracle, "bf16", True, 1, 16, 768, nwg=8, pairs=True, seed=2)
+
+
 def test_emulated_kernel_frequent_rescales_across_jobs(oracle):
     # a low deferral threshold makes every rare path (firing, deferred rescale) run in every step, across job seams
     rng = np.random.default_rng(4)
