@@ -110,8 +110,8 @@ S_QI, S_B, S_HH, S_UNIT, S_PASS, S_NT = S(81), S(83), S(84), S(85), S(86), S(87)
 S_T = tuple(S(88 + k) for k in range(8))  # temporaries s88..s95 (S_T[0] even: usable as a 64-bit pair)
 S_QROW = (S(96), S(97))          # first row of the wave's query block qb (current job)
 S_DBG = S(98, 2)
-S_NDESC, S_DESC = S(98), S(99)   # (product builds: the debug pointer's registers) causal head pairs: the next / the current job walks
-#                                  its non-diagonal key tiles in DESCENDING order (k_decode_next)
+S_NDESC, S_DESC = S(98), S(99)   # (product builds: the debug pointer's registers) causal: the next / the current job walks its
+#                                  non-diagonal key tiles in DESCENDING order (k_decode_next)
 S_KW, S_VW = S(100), S(101)      # 8 * wave * row stride: the wave's row base inside a tile
 S_KT0 = S(86)                    # (= S_PASS, causal only) non-causal ragged: real keys in the job's last 256 = N - 256 (nq - 1)
 S_LG = S(73)                     # decode shifts: lgH | lgG << 8 | lg(G * nunit) << 16 | pow2-mode << 24
@@ -161,14 +161,15 @@ class Gen:
         self.vm = 8 * min(self.dk - 3, self.dv - 2)  # DMA pieces that may stay in flight across the mid-step barrier
         self._cache = {}
         self.stamps = stamps   # diagnostic build: s_memtime stamps of the job timeline go to the debug buffer
-        # Causal HEAD PAIRS (the host sets bit 25 of the decode word when B * H is a multiple of 16): a unit is job (head A, query
-        # block nq - 1 - u) followed by job (head B, query block u), A and B being consecutive heads of the workgroup's XCD, and
-        # job B walks its non-diagonal key tiles DOWNWARDS.  The nq workgroups of a head pair then read K / V in lockstep: all
-        # start head A at tile 0 together and leave it behind their diagonal, i.e. after 4 (nq - u) steps; on head B workgroup u
-        # is at tile 4 nq - 1 - s at step s whatever its u -- so every K / V tile is fetched into the XCD's L2 once and read by the
-        # others within a step (with the two jobs of a unit on ONE head, the light job re-reads from tile 0 at a time of its own:
-        # K / V came from beyond L2 2.0 times, profiles/r02/c3_a64_rocprof.json).  The diagonal tiles stay the job's last four.
-        self.pairs = causal and not stamps and not ragged
+        # Causal, the LIGHT job of a unit walks DOWNWARDS (the host sets bit 25 of the decode word): a unit is the heavy job
+        # (query block nq - 1 - u, key tiles upwards) followed by the light job (query block u) of the same head.  All units of a head
+        # start their heavy job at tile 0 together and leave it behind their diagonal, after 4 (nq - u) steps; a light job that walks
+        # its non-diagonal tiles 4 u - 1 .. 0 downwards is at tile 4 nq - 1 - s at step s WHATEVER its u: the light jobs of a head
+        # form one stream in lockstep (each tile fetched once for all of them) that meets the tiles in the reverse of the order
+        # the heavy jobs left them in the XCD's L2 -- instead of every light job starting again at tile 0 at a time of its own
+        # (K / V came from beyond L2 2.0 times; profiles/r02/c3_a64_rocprof.json).  The diagonal tiles stay a job's last four,
+        # and the order is a function of (query block, nq) alone: a head's result does not depend on the launch it is part of.
+        self.down = causal and not stamps and not ragged
 
     # ------------------------------------------------------------------ small helpers
     def e(self, *insts):
@@ -425,9 +426,7 @@ class Gen:
           I("s_lshr_b32", t[1], S_LG, 8), I("s_and_b32", t[1], t[1], 255),    # lg G
           I("s_lshr_b32", S_UNIT, t[3], t[1]),                                # unit = r >> lgG
           I("s_lshl_b32", t[4], 1, t[1]), I("s_sub_u32", t[4], t[4], 1), I("s_and_b32", t[4], t[3], t[4]),   # r % G
-          I("s_lshl_b32", t[2], t[2], t[1]), I("s_add_u32", t[2], t[2], t[4]))
-        e(self.pair_head(t[2]))
-        e(I("s_lshl_b32", t[2], t[2], 3),
+          I("s_lshl_b32", t[2], t[2], t[1]), I("s_add_u32", t[2], t[2], t[4]), I("s_lshl_b32", t[2], t[2], 3),
           I("s_and_b32", t[0], S_JOB, 7), I("s_add_u32", bh, t[2], t[0]),
           I("s_and_b32", t[1], S_LG, 255),                                    # lg H
           I("s_lshr_b32", S_NB, bh, t[1]),
@@ -439,9 +438,7 @@ class Gen:
         e(I("s_lshr_b32", t[0], S_JOB, 3), I("s_mul_i32", t[1], S_G, S_NUNIT))
         self.udiv(t[2], t[3], t[0], t[1], vt)       # batch, r
         self.udiv(S_UNIT, t[4], t[3], S_G, vt)      # unit = r / G, r % G
-        e(I("s_mul_i32", t[2], t[2], S_G), I("s_add_u32", t[2], t[2], t[4]))
-        e(self.pair_head(t[2]))
-        e(I("s_lshl_b32", t[2], t[2], 3),
+        e(I("s_mul_i32", t[2], t[2], S_G), I("s_add_u32", t[2], t[2], t[4]), I("s_lshl_b32", t[2], t[2], 3),
           I("s_and_b32", t[0], S_JOB, 7), I("s_add_u32", bh, t[2], t[0]), I("s_branch", Label(l_done)))
         e(label(l_else))
         self.udiv(bh, S_UNIT, S_JOB, S_NUNIT, vt)
@@ -455,19 +452,11 @@ class Gen:
               I("s_sub_u32", S_NQI, S_NQ, 1), I("s_sub_u32", S_NQI, S_NQI, S_UNIT), I("s_branch", Label(l_pd)),
               label(l_p1), I("s_mov_b32", S_NQI, S_UNIT), label(l_pd),
               I("s_add_u32", t[0], S_NQI, 1), I("s_lshl_b32", S_NNT, t[0], 2))
-            if self.pairs:   # the second job of a head pair walks downwards (unless it is nothing but its diagonal)
+            if self.down:   # the light job of a unit walks downwards (unless it is nothing but its diagonal)
                 e(I("s_lshr_b32", t[0], S_LG, 25), I("s_and_b32", t[0], t[0], S_PASS), I("s_and_b32", t[0], t[0], 1),
                   I("s_cmp_lg_u32", S_NQI, 0), I("s_cselect_b32", S_NDESC, t[0], 0))
         else:
             e(I("s_mov_b32", S_NQI, S_UNIT), I("s_lshl_b32", S_NNT, S_NQ, 2))      # (4 tiles per 256 rows, N rounded up)
-
-    def pair_head(self, x):
-        """head pairs: x = index of the head pair among its XCD's -> index of the head: 2 x + pass (a no-op without bit 25)"""
-        if not self.pairs:
-            return []
-        pm = S_T[0]     # (dead at both call sites; S_T[5] is the epilogue's store offset while the next job is decoded)
-        return [I("s_lshr_b32", pm, S_LG, 25), I("s_and_b32", pm, pm, 1), I("s_lshl_b32", x, x, pm),
-                I("s_and_b32", pm, pm, S_PASS), I("s_add_u32", x, x, pm)]
 
     def k_advance(self, vt=None):
         """S_JOB / S_PASS -> the job after the most recently decoded one, decoded into the next-job registers;
@@ -476,14 +465,11 @@ class Gen:
         e = self.e
         l_fin, l_ok = self.lab("adv_final"), self.lab("adv_ok")
         if self.causal:
-            l_adv, l_p1 = self.lab("adv"), self.lab("adv_pass1")
-            # pass 0 -> pass 1 of the same unit unless the pair is a single tile (nq odd, middle: not with head pairs, whose
-            # second job belongs to another head)
-            e(I("s_cmp_lg_u32", S_PASS, 0), I("s_cbranch_scc1", Label(l_adv)))
-            if self.pairs:
-                e(I("s_bitcmp1_b32", S_LG, 25), I("s_cbranch_scc1", Label(l_p1)))
-            e(I("s_sub_u32", S_T[0], S_NQ, 1), I("s_sub_u32", S_T[0], S_T[0], S_UNIT), I("s_cmp_eq_u32", S_T[0], S_UNIT),
-              I("s_cbranch_scc1", Label(l_adv)), label(l_p1),
+            l_adv = self.lab("adv")
+            # pass 0 -> pass 1 of the same unit unless the pair is a single tile (nq odd, middle)
+            e(I("s_cmp_lg_u32", S_PASS, 0), I("s_cbranch_scc1", Label(l_adv)),
+              I("s_sub_u32", S_T[0], S_NQ, 1), I("s_sub_u32", S_T[0], S_T[0], S_UNIT), I("s_cmp_eq_u32", S_T[0], S_UNIT),
+              I("s_cbranch_scc1", Label(l_adv)),
               I("s_mov_b32", S_PASS, 1), I("s_branch", Label(l_ok)),
               label(l_adv), I("s_mov_b32", S_PASS, 0), I("s_add_u32", S_JOB, S_JOB, S_NWG))
         else:
@@ -494,11 +480,11 @@ class Gen:
         e(I("s_branch", Label(l_done)), label(l_fin),
           comment("no further job: the seam streams the current job's first tiles again (results discarded)"),
           I("s_mov_b32", S_FINAL, 1), I("s_mov_b32", S_NB, S_B), I("s_mov_b32", S_NHH, S_HH), I("s_mov_b32", S_NQI, S_QI),
-          I("s_mov_b32", S_NNT, S_NT), ([I("s_mov_b32", S_NDESC, S_DESC)] if self.pairs else []), label(l_done))
+          I("s_mov_b32", S_NNT, S_NT), ([I("s_mov_b32", S_NDESC, S_DESC)] if self.down else []), label(l_done))
 
     def k_promote(self):
         """next job -> current job"""
-        self.e(([I("s_mov_b32", S_DESC, S_NDESC)] if self.pairs else []),
+        self.e(([I("s_mov_b32", S_DESC, S_NDESC)] if self.down else []),
                I("s_mov_b32", S_B, S_NB), I("s_mov_b32", S_HH, S_NHH), I("s_mov_b32", S_QI, S_NQI), I("s_mov_b32", S_NT, S_NNT),
                # query rows of this wave: qrow[qb] = 256 qi + 64 wave + 32 qb  (split row map: 256 qi + 32 wave + 128 qb)
                I("s_lshl_b32", S_T[0], S_QI, 8), I("s_lshl_b32", S_T[1], S_WAVE, 5 if self.split else 6),
@@ -523,10 +509,10 @@ class Gen:
         return out + pre + [I("s_nop", 0), ld]
 
     def stream_start(self, which):
-        """head pairs: start offset and step of the NEXT job's K / V tile stream -- upwards from tile 0, or (S_NDESC) downwards from
+        """causal: start offset and step of the NEXT job's K / V tile stream -- upwards from tile 0, or (S_NDESC) downwards from
         the tile under the diagonal span, 4 qi - 1.  S_K64 / S_V64 hold the signed step of the running stream"""
         dma, w0, s32, step = (S_KDMA, S_KW, S_K32, S_K64) if which == "k" else (S_VDMA, S_VW, S_V32, S_V64)
-        if not self.pairs:
+        if not self.down:
             return [I("s_mov_b32", dma, w0)]
         t0, t1 = S_T[6], S_T[7]     # (the 64-bit multiply's scratch: free between scalar units; S_T[2..4] belong to the Q staging)
         return [I("s_lshl_b32", t0, s32, 1), I("s_lshl_b32", t1, S_NQI, 2), I("s_sub_u32", t1, t1, 1), I("s_mul_i32", t1, t1, t0),
@@ -534,9 +520,9 @@ class Gen:
                 I("s_sub_u32", t1, 0, t0), I("s_cmp_lg_u32", S_NDESC, 0), I("s_cselect_b32", step, t1, t0)]
 
     def stream_to_diagonal(self, which):
-        """head pairs, the steady loop's last trip: the stream has reached the job's diagonal span -- tiles 4 qi .. 4 qi + 3, upwards
+        """causal, the steady loop's last trip: the stream has reached the job's diagonal span -- tiles 4 qi .. 4 qi + 3, upwards
         (for a job that walks upwards this is where it stood anyway)"""
-        if not self.pairs:
+        if not self.down:
             return []
         dma, w0, s32, step = (S_KDMA, S_KW, S_K32, S_K64) if which == "k" else (S_VDMA, S_VW, S_V32, S_V64)
         t0, t1 = S_T[6], S_T[7]

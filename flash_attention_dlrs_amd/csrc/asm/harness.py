@@ -35,7 +35,7 @@ def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, n
     ispow2 = lambda x: x > 0 and (x & (x - 1)) == 0
     if pow2 and nbh % 8 == 0 and ispow2(H) and ispow2(G) and ispow2(G * nunit):
         lg = (H.bit_length() - 1) | ((G.bit_length() - 1) << 8) | (((G * nunit).bit_length() - 1) << 16) | (1 << 24)
-    if pairs:      # causal head pairs (fa2_a64.hip: B * H a multiple of 16)
+    if pairs:      # causal: the light job of a unit walks its non-diagonal key tiles downwards (fa2_a64.hip)
         lg |= 1 << 25
     b += struct.pack("<II", lg, 0)
     assert len(b) == KARG_SIZE, len(b)
@@ -59,9 +59,7 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     nunit = (nq + 1) // 2 if causal else nq
     nbh = B * H
     total = nunit * nbh
-    if pairs:      # a unit = (head A, query block nq - 1 - u) then (head B, query block u, walked downwards): fa2_a64_gen.Gen.pairs
-        assert causal and nbh % 16 == 0 and G == 1
-        nunit, total = nq, nq * nbh // 2
+    assert causal or not pairs
     nwg = nwg or min(total, 256)
     sb, sh, sn = H * N * D * 2, N * D * 2, D * 2
     thr = A64_THR[dtype]

@@ -30,7 +30,7 @@ struct __attribute__((packed)) A64Args {
     int32_t nunit, group;
     int32_t nbh, nwg;
     void *dbg;
-    uint32_t lg;   // lgH | lgG << 8 | lg(G * nunit) << 16 | 1 << 24 when those are powers of two and B * H % 8 == 0; bit 25: head pairs
+    uint32_t lg;   // lgH | lgG << 8 | lg(G * nunit) << 16 | 1 << 24 when those are powers of two and B * H % 8 == 0; bit 25: light causal jobs walk downwards
     uint32_t pad;
 };
 static_assert(sizeof(A64Args) == 192, "kernel-argument layout");
@@ -153,27 +153,21 @@ int launch(const Fa2Problem &p, int shape16) {
         while (per_xcd % g) --g;
         a.group = g;
     }
-    // Causal HEAD PAIRS (asm/fa2_a64_gen.py, Gen.pairs): a unit = job (head A, query block nq - 1 - u), then job (head B, query
-    // block u) with its non-diagonal key tiles walked downwards, A and B consecutive heads of the unit's XCD.  The nq workgroups of
-    // a pair then stream K / V in lockstep (each tile enters the XCD's L2 once); needs B * H a multiple of 16.
-    // Measured (profiles/r03/pairs_ab.jsonl, same-device A/B): N = 2048 +2.8 %, N = 4096 (c3) +1.1 % -- K / V from beyond L2 2.04 ->
-    // 1.47 times (what is left: job B's diagonal tiles, read after its stream has passed them); N = 8192 -0.6 %, N = 16384 0:
-    // with more than 16 workgroups per pair a pair no longer fits beside another on an XCD.
-    bool pairs = p.causal && (a.nbh % 16) == 0 && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && !shape16;
+    // Causal: the LIGHT job of a unit walks its non-diagonal key tiles downwards (asm/fa2_a64_gen.py, Gen.pairs): the light jobs of
+    // a head then form one stream in lockstep that meets the tiles in the reverse of the order the heavy jobs left them in L2,
+    // instead of each starting again at tile 0 at a time of its own.  The order is a function of (query block, nq) alone, so a
+    // head's result does not depend on the launch it is part of (bit-identical head sharding).  Same-device A/B against
+    // FA2_A64_PAIRS=0 (profiles/r03/pairs_ab.jsonl): c3 +1 %, N = 2048 +2.8 %, N >= 8192 0 .. -0.6 % (left alone there).
+    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && !shape16;
 #ifdef FA2_A64_STAMPS
-    pairs = false;      // (the diagnostic kernels use the pair registers for the debug pointer)
+    down = false;      // (the diagnostic kernels use the registers for the debug pointer)
 #endif
 #ifdef FA2_A64_VARIANTS
     {
-        const char *pv = getenv("FA2_A64_PAIRS");     // A/B runs: FA2_A64_PAIRS=0 keeps both jobs of a unit on one head
-        if (pv && *pv == '0') pairs = false;
+        const char *pv = getenv("FA2_A64_PAIRS");     // A/B runs: FA2_A64_PAIRS=0: every job walks upwards
+        if (pv && *pv == '0') down = false;
     }
 #endif
-    if (pairs) {
-        a.group = 1;
-        a.nunit = a.nq;
-        a.total = a.nq * (a.nbh / 2);
-    }
     // persistent grid: one workgroup per CU, a multiple of 8 when there is more work than CUs (XCD affinity of the units)
     int slots = d->cus - d->cus % 8;
     if (slots < 8) slots = 8;
@@ -185,7 +179,7 @@ int launch(const Fa2Problem &p, int shape16) {
         const int gn = a.group * a.nunit;
         a.lg = ((a.nbh & 7) == 0 && pow2(p.H) && pow2(a.group) && pow2(gn))
                    ? (uint32_t)(lg2(p.H) | (lg2(a.group) << 8) | (lg2(gn) << 16) | (1 << 24)) : 0u;
-        if (pairs) a.lg |= 1u << 25;
+        if (down) a.lg |= 1u << 25;
         a.pad = 0;
     }
 #ifdef FA2_A64_VARIANTS
