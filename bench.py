@@ -109,6 +109,37 @@ def cpu_baseline(c, budget_s=12.0):
                                "sample": f"same sample under SDPBackend.MATH, {reps_m} reps in {el_m:.1f}s"}
     except Exception as e:
         out["math_backend"] = {"error": str(e)[:100]}
+    # configs[0] (c1) and configs[1] (c2) timed FULLY in both flavours, configs[2] (c3) at one full repetition
+    # of the default backend (its MATH flavour materialises 4 x 32 x 4096^2 fp32 scores: the sample above stands for it)
+    full = {}
+    for name, cc, reps in (("c1", dict(B=1, H=2, N=128, d=64, causal=False), 200), ("c2", dict(B=2, H=8, N=1024, d=64, causal=False), 10),
+                           ("c3", dict(B=4, H=32, N=4096, d=128, causal=True), 1)):
+        try:
+            g2 = torch.Generator().manual_seed(42)
+            q, k, v = (torch.randn(cc["B"], cc["H"], cc["N"], cc["d"], generator=g2) for _ in range(3))
+            f = lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v, scale=1.0, is_causal=cc["causal"])
+            for _ in range(3 if name != "c3" else 0):
+                f()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            ms = (time.perf_counter() - t0) * 1e3 / reps
+            ent = {"shape": f"B={cc['B']} H={cc['H']} N={cc['N']} d={cc['d']} fp32 causal={cc['causal']}", "reps": reps,
+                   "ms": round(ms, 4), "gflops": round(flops(cc) / ms / 1e6, 2)}
+            if name != "c3":
+                from torch.nn.attention import SDPBackend, sdpa_kernel
+                with sdpa_kernel(SDPBackend.MATH):
+                    f()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        f()
+                ms_m = (time.perf_counter() - t0) * 1e3 / reps
+                ent["math_backend"] = {"ms": round(ms_m, 4), "gflops": round(flops(cc) / ms_m / 1e6, 2)}
+            full[name] = ent
+            del q, k, v
+        except Exception as e:
+            full[name] = {"error": str(e)[:100]}
+    out["full_configs"] = full
     # the oracle's scalar C port, one core, on a smaller slice (N^2 work: keep it to a few seconds)
     try:
         from oracle import fa2_oracle

@@ -57,6 +57,27 @@ def pad_last_dim(t, d_proper):
     return torch.nn.functional.pad(t, (0, d_proper - d), mode="constant", value=0.0)
 
 
+def forward_head_size(dtype, B, H, N, d):
+    """Head size the forward kernels are RUN at.  The kernels take any d (the reference pads every d that is not a power of two,
+    torch.py:38-47), but only some on the matrix cores: f16 / bf16 multiples of 8 and fp32 multiples of 4 up to 128.  Everything
+    else would run on the VALU kernel, 60-90 times slower than a zero-padded launch (profiles/r03/pad_vs_predicated.jsonl: bf16
+    B4 H32 N4096 d = 100: 87.5 ms as it is, 0.98 ms padded to 128, the three pad copies and the slice of O included).  So:
+      * f16 / bf16, d not a multiple of 8: pad to 64 (d < 64) or 128 -- the pipelined kernels; as fast as or faster than the next
+        multiple of 8 on every shape measured;
+      * f16 / bf16, 64 < d < 128 a multiple of 8: the d-predicated kernel as it is on small grids (29 vs 45 us at B2 H8 N1024), padded
+        to 128 from 128 Ki rows on (B4 H32 N4096 d = 96: 1.08 -> 0.90 ms);
+      * fp32, d not a multiple of 4: the next multiple of 4 (the predicated fp32 MFMA kernel).
+    Zero-padding is exact: the extra products are zeros, the extra columns of O are sliced away (torch.py:81-82)."""
+    if dtype in (torch.float16, torch.bfloat16) and d <= 128:
+        if d % 8:
+            return 64 if d < 64 else 128
+        if 64 < d < 128 and B * H * N >= 131072:
+            return 128
+    if dtype == torch.float32 and d <= 128 and d % 4:
+        return (d + 3) // 4 * 4
+    return d
+
+
 def _check_inputs(Q, K, V):
     dev = Q.device
     if dev.type != "cuda" or dev != K.device or dev != V.device:
@@ -74,19 +95,27 @@ def _forward_impl(ctx, Q, K, V, causal, scale):
 
     # Non-power-of-2 d or d < 16: the reference pads Q, K, V on the host (torch.py:38-47) and returns the O[..., :d] view
     # of a padded O.  The forward kernels take any d (the MFMA kernels zero-fill the missing
-    # columns on load, the generic kernel loops to d): no copies here, O comes back with exactly d columns.  Only the
-    # backward still wants a power of two and pads what it was handed (_backward_impl).
+    # columns on load, the generic kernel loops to d): head sizes the matrix cores take run as they are, O comes back with
+    # exactly d columns; the others are padded as the reference pads them (forward_head_size).  The backward still wants a
+    # power of two and pads what it was handed (_backward_impl).
     d_proper = max(next_power_of_2(d), MIN_TENSOR_SIZE)
     padded = d_proper != d
+    d_run = forward_head_size(Q.dtype, B, H, N, d)
 
     # O inherits Q's strides, L is (B, H, N, 1) in the input dtype (reference torch.py:50-51)
-    O = torch.empty_like(Q)
     L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=Q.device)
-
-    # static gfx950 tile table, or the on-box tuner's choice when FA2_AUTOTUNE=1 (autotune.py; reference:
-    # the Triton autotuner keyed on (B, H, N, d), kernels.py:11-15)
-    _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale,
-                 variant=autotune.pick(Q, K, V, O, L, dtype, causal, scale))
+    if d_run != d:
+        Qr, Kr, Vr = (pad_last_dim(t, d_run) for t in (Q, K, V))
+        Or = torch.empty_like(Qr)
+        _lib.fa2_fwd(Qr, Kr, Vr, Or, L, dtype, causal=causal, scale=scale,
+                     variant=autotune.pick(Qr, Kr, Vr, Or, L, dtype, causal, scale))
+        O = Or[..., :d]        # (a view of the padded O, as the reference returns it: torch.py:81-82)
+    else:
+        O = torch.empty_like(Q)
+        # static gfx950 tile table, or the on-box tuner's choice when FA2_AUTOTUNE=1 (autotune.py; reference:
+        # the Triton autotuner keyed on (B, H, N, d), kernels.py:11-15)
+        _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale,
+                     variant=autotune.pick(Q, K, V, O, L, dtype, causal, scale))
 
     ctx.save_for_backward(Q, K, V, O, L)
     ctx.padded = padded

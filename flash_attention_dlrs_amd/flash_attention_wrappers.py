@@ -6,8 +6,8 @@ script (src/test_correctness.py:34) and the only place the log2-domain log-sum-e
 import torch
 
 from . import _lib, autotune
-from .flash_attention_torch import (MIN_TENSOR_SIZE, backward_native, convert_triton_dtype, next_power_of_2,
-                                    pad_last_dim)
+from .flash_attention_torch import (MIN_TENSOR_SIZE, backward_native, convert_triton_dtype, forward_head_size,
+                                    next_power_of_2, pad_last_dim)
 
 
 def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="auto"):
@@ -20,7 +20,14 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
     B, H, N, d = Q.shape
 
     # The reference pads Q, K, V to next_pow2(d) here (wrappers.py:27-34) and slices O afterwards; the kernels take any d
-    # (SURVEY section 8 row f2), so nothing is copied and O has exactly d columns.
+    # (SURVEY section 8 row f2): head sizes the matrix cores take run as they are (nothing copied, O has exactly d columns), the
+    # others are padded as the reference pads them -- 60-90 times faster than the VALU kernel they would fall to
+    # (forward_head_size).  A forced variant gets the tensors as they are.
+    d_out = d
+    if variant == "auto":
+        d = forward_head_size(Q.dtype, B, H, N, d)
+        if d != d_out:
+            Q, K, V = (pad_last_dim(t, d) for t in (Q, K, V))
 
     # Always-contiguous outputs (reference wrappers.py:37-38)
     O = torch.empty(B, H, N, d, dtype=Q.dtype, device=dev)
@@ -35,14 +42,14 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
         if v != _lib.VARIANT_AUTO:
             try:
                 _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
-                return O, L
+                return O[..., :d_out], L
             except TypeError:
                 # the tuned variant cannot run THIS problem (strides, alignment, N * stride >= 2 GiB: the tuner's key does
                 # not see them): the static table can, it falls back to the kernels that take any layout
                 v = _lib.VARIANT_AUTO
     _lib.fa2_fwd(Q, K, V, O, L, dtype, causal=causal, scale=scale, variant=v)
 
-    return O, L
+    return O[..., :d_out], L     # (reference wrappers.py:63)
 
 
 def flash_attention_backward(Q, K, V, O, dO, L, dev, deterministic=False, *, causal=False, scale=1.0, variant="auto"):

@@ -193,15 +193,26 @@ def test_head_sizes_that_are_not_powers_of_two_vs_oracle(oracle, dtype, d, causa
         check_L(Lv.cpu(), L_ref, dtype)
 
 
-def test_odd_head_sizes_fall_back_to_the_generic_kernel(oracle):
+def test_odd_head_sizes(oracle):
+    """head sizes no MFMA kernel takes: at the C ABI they run on the generic kernel; the Python surface pads them on the host (as
+    the reference does, torch.py:38-47) so that they stay on the matrix cores, and returns the [:d] view"""
     assert _lib.query_tile(70, 40, _lib.FA2_DTYPE_F8E5M2, False, B=1, H=2)[0] == _lib.VARIANT_GENERIC
-    for dtype, d in ((torch.float32, 37), (torch.float16, 20), (torch.bfloat16, 1), (torch.float32, 130)):
+    for dtype, d in ((torch.float32, 37), (torch.float16, 20), (torch.bfloat16, 1), (torch.float32, 130), (torch.bfloat16, 100)):
         Q, K, V = _rand((1, 2, 70, d), dtype, seed=d, spread=0.5)
         assert _lib.query_tile(70, d, fa.convert_triton_dtype(dtype), False, B=1, H=2)[0] == _lib.VARIANT_GENERIC
-        O, L = hip_forward(Q, K, V)
         O_ref, L_ref = _oracle(oracle, Q, K, V, dtype, False)
-        check_O(O, O_ref, dtype)
-        check_L(L, L_ref, dtype)
+        for variant in ("auto", "generic"):      # (a forced variant gets the tensors as they are)
+            O, L = hip_forward(Q, K, V, variant=variant)
+            assert O.shape == Q.shape
+            check_O(O, O_ref, dtype)
+            check_L(L, L_ref, dtype)
+        Oa = fa.FlashAttention.apply(Q.to(DEV), K.to(DEV), V.to(DEV)).cpu()
+        check_O(Oa, O_ref, dtype)
+    # large grid, 64 < d < 128 a multiple of 8: padded to 128 (the pipelined kernels); the result is the predicated kernel's
+    Q, K, V = _rand((4, 32, 1024, 96), torch.bfloat16, seed=96, spread=0.5)
+    O, _ = hip_forward(Q, K, V, causal=True)
+    O2, _ = hip_forward(Q, K, V, causal=True, variant="mfma16")
+    assert O.shape == Q.shape and (O.float() - O2.float()).abs().max() <= 2 * O_TOL[torch.bfloat16]
 
 
 def test_golden_strided_inputs_and_stride_inheritance():

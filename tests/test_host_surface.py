@@ -119,6 +119,19 @@ def test_autotune_key_and_table_roundtrip(tmp_path, monkeypatch):
     assert autotune.pick(Q, Q, Q, Q, Q, _lib.FA2_DTYPE_BF16, True, 1.0) == _lib.VARIANT_AUTO
 
 
+def test_forward_head_size_keeps_odd_head_sizes_on_the_matrix_cores():
+    """head sizes the MFMA kernels do not take (f16 / bf16 not a multiple of 8, fp32 not a multiple of 4) are padded on the
+    host, as the reference pads (torch.py:38-47), instead of falling to the VALU kernel; eligible ones run as they are"""
+    f = ft.forward_head_size
+    for dt in (torch.float16, torch.bfloat16):
+        assert [f(dt, 4, 32, 4096, d) for d in (100, 36, 20, 1, 63, 65, 127)] == [128, 64, 64, 64, 64, 128, 128]
+        assert [f(dt, 2, 8, 1024, d) for d in (8, 24, 40, 48, 64, 80, 96, 120, 128, 136, 256)] == [8, 24, 40, 48, 64, 80, 96, 120, 128, 136, 256]
+        assert [f(dt, 4, 32, 4096, d) for d in (40, 64, 80, 96, 120, 128)] == [40, 64, 128, 128, 128, 128]     # large grids: the pipelined kernels
+    assert [f(torch.float32, 1, 2, 70, d) for d in (37, 50, 30, 96, 40, 8, 130)] == [40, 52, 32, 96, 40, 8, 130]
+    for dt in (torch.float64, torch.float8_e5m2, torch.float8_e4m3fn):
+        assert f(dt, 1, 2, 70, 37) == 37
+
+
 def test_bench_self_launch_relays_the_ranks_exit_code_without_a_gpu():
     """bench.py --gpus 2 outside torch.distributed.run starts its own rank processes; on a box without GPUs the ranks fail and
     the parent must hand their failure on (non-zero exit, no result line) instead of crashing or printing a made-up line"""
