@@ -10,6 +10,8 @@ every instruction in between counts one, `s_nop N` counts N + 1):
   R6  VALU-written SGPR (v_readfirstlane, v_cmp) -> memory instruction reading it: >= 5 (SALU readers are interlocked)
   R7  SALU write of M0 -> LDS-DMA: >= 1
   R8  MFMA C operand -> overwritten by VALU: >= 12
+  R10 vector-memory store of more than 64 bits of data -> VALU write of those data registers: >= 2 (the store reads its data
+      after it has issued; nothing in the generated streams is that close today -- the rule guards schedule edits)
   R9  (not a wait state: a scheduling invariant) the SCC an instruction consumes was produced by the instruction meant to
       produce it -- s_addc_u32 by the s_add_u32 of the low half of its own register pair, s_cselect / s_cbranch_scc* by a
       compare -- with no label in between.  Interleaving scalar sequences into MFMA gaps one instruction at a time broke a
@@ -29,7 +31,7 @@ def wait_states(ins: Inst) -> int:
     return 1
 
 
-REQUIRED = {"R1": 12, "R2": 2, "R3": 1, "R4": 2, "R5": 1, "R6": 5, "R7": 1, "R8": 12}
+REQUIRED = {"R1": 12, "R2": 2, "R3": 1, "R4": 2, "R5": 1, "R6": 5, "R7": 1, "R8": 12, "R10": 2}
 
 
 def fix(prog, max_rounds=64):
@@ -153,6 +155,7 @@ def check(prog, verbose=True):
     last_trans_def = {}
     last_valu_sgpr = {}
     last_m0 = -100
+    last_wide_store = {}  # data reg -> pos of a store of more than 64 bits that reads it
     pos = 0
     errs = []
     for idx, ins in enumerate(prog):
@@ -195,6 +198,8 @@ def check(prog, verbose=True):
                 for r in d:
                     if r in last_mfma_csrc and dist(last_mfma_csrc[r]) < 12:
                         errs.append((idx, "R8 mfma C overwritten", r, dist(last_mfma_csrc[r])))
+                    if r in last_wide_store and dist(last_wide_store[r]) < 2:
+                        errs.append((idx, "R10 store data overwritten", r, dist(last_wide_store[r])))
                 if ins.op not in TRANS_OPS:
                     for r in u:
                         if r in last_trans_def and dist(last_trans_def[r]) < 1:
@@ -214,6 +219,10 @@ def check(prog, verbose=True):
                 for r in u:
                     if r[0] == "s" and r in last_valu_sgpr and dist(last_valu_sgpr[r]) < 5:
                         errs.append((idx, "R6 valu sgpr->reader", r, dist(last_valu_sgpr[r])))
+            if ins.op in ("buffer_store_dwordx4", "buffer_store_dwordx3", "global_store_dwordx4", "global_store_dwordx3"):
+                data = ins.ops[0] if ins.op.startswith("buffer_") else ins.ops[1]
+                for r in data.regs():
+                    last_wide_store[r] = here
             if ins.op.startswith("buffer_load") and ins.mods.get("lds") and dist(last_m0) < 1:
                 errs.append((idx, "R7 m0->lds dma", ("s", 124), dist(last_m0)))
             for r in d:

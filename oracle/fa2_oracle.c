@@ -155,7 +155,7 @@ int fa2_oracle_fwd(const float *Q, const float *K, const float *V, float *O, flo
  *
  *   deferred running maximum   :93/:95/:99 raise m for every tile.  The kernels keep m while no row of a G-row group
  *                              (one wave's query block) has rowmax(S) - m > thr, so P = exp2(S - m) may reach 2^thr
- *                              (fa2_a64.hip: thr = 60 bf16 / 12 f16; fa2_mfma8x.hip: kThr = 6); when one does, every
+ *                              (fa2_a64.hip: thr = 60 bf16 / 15.875 f16; fa2_mfma8x.hip: kThr = 6); when one does, every
  *                              row of the group takes m' = max(m, rowmax(S)).  thr < 0 raises m for every tile (= :93).
  *   one rounding in S - m      exp2(fma(dot, c, -m)) instead of :92 + :94's two roundings;
  *   sum_rounded != 0           l accumulates cast(P) (the row sums ride on the matrix pipe with the rounded P) instead

@@ -172,6 +172,25 @@ def test_rescale_branch_is_exercised(oracle, dtype, variant):
         check(*a64(Q, K, V, causal, variant=variant), *oracle_fwd(oracle, Q, K, V, dtype, causal), dtype)
 
 
+@both
+def test_large_magnitude_V_stays_finite(oracle, variant):
+    """bf16 defers the running maximum by up to 60 log2 units, so P may reach 2^60 before a rescale and the fp32 O
+    accumulator holds sum(P |V|): finite while |V| stays below about 2^68 / N (3e16 at N = 4096) -- the documented bound
+    (the reference, with P <= 1, takes any bf16 V).  |V| ~ 1e15 with a row maximum that jumps late, against the
+    plain oracle (relative to the scale of V)"""
+    dtype, scale_v = torch.bfloat16, 1e15
+    Q, K, V = rand3((1, 2, 1024, 128), torch.float32, seed=41, spread=0.6)
+    K[:, :, 900] = Q[:, :, 100] * 3.0          # row 100's maximum moves by ~60 log2 units in the last tiles
+    V = V * scale_v
+    Q, K, V = (t.to(dtype) for t in (Q, K, V))
+    for causal in (False, True):
+        O, L = a64(Q, K, V, causal, variant=variant)
+        O_ref, L_ref = oracle_fwd(oracle, Q, K, V, dtype, causal)
+        assert torch.isfinite(O.float()).all()
+        assert ((O.float() - O_ref) / scale_v).abs().max() <= O_TOL[dtype]
+        assert (L.float().flatten() - L_ref.flatten()).abs().max() <= 1.01 * ulp(dtype, L_ref.abs().max().item())
+
+
 @pytest.mark.parametrize("variant", ["a64", "a16", "mfma16h", "mfma16"])
 def test_tensors_that_straddle_a_4_gib_address_boundary(variant):
     """every 64-bit address the kernels form (descriptor base + b * stride_b + h * stride_h) must carry out of its low word:

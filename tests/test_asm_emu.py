@@ -35,6 +35,28 @@ def test_generated_stream_has_no_wait_state_violation(dtype, causal):
     assert check(p, verbose=False) == []
 
 
+@pytest.mark.parametrize("kw", [dict(ragged=True, causal=False), dict(ragged=True, causal=True), dict(split=False, causal=True)])
+def test_the_other_shipped_and_ab_streams_have_no_wait_state_violation(kw):
+    """the ragged kernels ship in the same code object, the contiguous row map is the A/B variant of the experiments build"""
+    kw = dict(kw)
+    g = Gen("bf16", kw.pop("causal"), **kw)
+    assert check(g.build(), verbose=False) == []
+
+
+def test_store_data_hazard_rule():
+    """check.py R10: a VALU write of the data registers of a store wider than 64 bits needs two wait states behind the store"""
+    from flash_attention_dlrs_amd.csrc.asm.check import fix
+    from flash_attention_dlrs_amd.csrc.asm.isa import I, S, V
+    st = I("buffer_store_dwordx4", V(8, 4), V(20), S(60, 4), S(88), offen=1)
+    bad = [st, I("v_mov_b32", V(9), 0)]
+    assert [e[1] for e in check(bad, verbose=False)] == ["R10 store data overwritten"]
+    assert len(check([st, I("s_nop", 0), I("v_mov_b32", V(9), 0)], verbose=False)) == 1      # one wait state is not enough
+    assert check([st, I("s_nop", 1), I("v_mov_b32", V(9), 0)], verbose=False) == []
+    assert check([st, I("v_mov_b32", V(20), 0)], verbose=False) == []          # the address register is read at issue
+    fixed, added = fix(bad)
+    assert added == 2 and check(fixed, verbose=False) == []
+
+
 def test_generated_module_assembles_for_gfx950(tmp_path):
     clang = "/opt/rocm/lib/llvm/bin/clang"
     if not os.path.exists(clang):
