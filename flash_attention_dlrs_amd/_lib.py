@@ -21,21 +21,30 @@ VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA16, VARIANT_MFMA16_W8, VARIANT_MFMA32
 VARIANT_MFMA16K_R2K4 = 23  # 21 / 22 are the experimental MFMA16P schedules
 VARIANT_A64 = 24
 VARIANT_A16 = 25
-VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_MFMA16,
-            "mfma16_w8": VARIANT_MFMA16_W8, "mfma32": VARIANT_MFMA32, "mfma16p": VARIANT_MFMA16P,
-            "mfma16p_w8": VARIANT_MFMA16P_W8, "mfma16x": VARIANT_MFMA16X, "mfma16d": VARIANT_MFMA16D, "mfma16d_w4": VARIANT_MFMA16D_W4, "mfma16h": VARIANT_MFMA16H, "mfma16h_w4": VARIANT_MFMA16H_W4, "mfma16s": VARIANT_MFMA16S, "mfma16s_w4": VARIANT_MFMA16S_W4, "mfma8": VARIANT_MFMA8, "mfma8_w4": VARIANT_MFMA8_W4, "mfma8x": VARIANT_MFMA8X, "mfma8x_w4": VARIANT_MFMA8X_W4, "mfma8u": VARIANT_MFMA8U, "mfma16k": VARIANT_MFMA16K, "mfma16k_r2k2": VARIANT_MFMA16K_R2K2, "mfma16k_r2k4": VARIANT_MFMA16K_R2K4, "a64": VARIANT_A64, "a16": VARIANT_A16, "mfma16p_x1": VARIANT_MFMA16P + 16,
-            "mfma16p_w8_x1": VARIANT_MFMA16P_W8 + 16,
-            # timing-only ablations, present only in -DFA2_ABLATIONS builds of the library
-            "abl_noexp": VARIANT_MFMA16P_W8 + 32, "abl_nosum": VARIANT_MFMA16P_W8 + 64,
-            "abl_nomax": VARIANT_MFMA16P_W8 + 128, "abl_all": VARIANT_MFMA16P_W8 + 224,
-            "abl_nobar": VARIANT_MFMA16P_W8 + 256, "abl_noload": VARIANT_MFMA16P_W8 + 512,
-            "abl_skeleton": VARIANT_MFMA16P_W8 + 736, "abl_nobar_only": VARIANT_MFMA16P_W8 + 192 * 16,
-            "mfma16p_w8_x2": VARIANT_MFMA16P_W8 + 1024, "mfma16p_x2": VARIANT_MFMA16P + 1024,
-            "x_noexp": VARIANT_MFMA16X + 2048 * 1, "x_nosoftmax": VARIANT_MFMA16X + 2048 * 3,
-            "x_nolds": VARIANT_MFMA16X + 2048 * 4, "x_mfma_only": VARIANT_MFMA16X + 2048 * 7,
-            "x_nostage": VARIANT_MFMA16X + 2048 * 8, "x_bare": VARIANT_MFMA16X + 2048 * 15,
-            "x_nobar": VARIANT_MFMA16X + 2048 * 16, "x_noload": VARIANT_MFMA16X + 2048 * 32,
-            "x_nobar_noload": VARIANT_MFMA16X + 2048 * 48}
+# The variants include/fa2_fwd.h publishes -- what libfa2_hip.so runs.
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_MFMA16, "mfma16_w8": VARIANT_MFMA16_W8,
+            "mfma32": VARIANT_MFMA32, "mfma16d": VARIANT_MFMA16D, "mfma16d_w4": VARIANT_MFMA16D_W4, "mfma16h": VARIANT_MFMA16H,
+            "mfma16h_w4": VARIANT_MFMA16H_W4, "mfma8x": VARIANT_MFMA8X, "mfma8x_w4": VARIANT_MFMA8X_W4, "mfma16k": VARIANT_MFMA16K,
+            "mfma16k_r2k2": VARIANT_MFMA16K_R2K2, "mfma16k_r2k4": VARIANT_MFMA16K_R2K4, "a64": VARIANT_A64, "a16": VARIANT_A16}
+# Experimental kernels, A/B baselines and timing-only ablations: they exist only in the experiments / ablation builds of the library
+# (`make -C flash_attention_dlrs_amd/csrc experiments|abl`, csrc/fa2_experiments.h), which benchmarks/ load through FA2_HIP_LIB --
+# the names are published only when such a build is the one loaded.
+EXPERIMENTAL_VARIANTS = {
+    "mfma16p": VARIANT_MFMA16P, "mfma16p_w8": VARIANT_MFMA16P_W8, "mfma16x": VARIANT_MFMA16X, "mfma16s": VARIANT_MFMA16S,
+    "mfma16s_w4": VARIANT_MFMA16S_W4, "mfma8": VARIANT_MFMA8, "mfma8_w4": VARIANT_MFMA8_W4, "mfma8u": VARIANT_MFMA8U,
+    "mfma16p_x1": VARIANT_MFMA16P + 16, "mfma16p_w8_x1": VARIANT_MFMA16P_W8 + 16,
+    "abl_noexp": VARIANT_MFMA16P_W8 + 32, "abl_nosum": VARIANT_MFMA16P_W8 + 64,
+    "abl_nomax": VARIANT_MFMA16P_W8 + 128, "abl_all": VARIANT_MFMA16P_W8 + 224,
+    "abl_nobar": VARIANT_MFMA16P_W8 + 256, "abl_noload": VARIANT_MFMA16P_W8 + 512,
+    "abl_skeleton": VARIANT_MFMA16P_W8 + 736, "abl_nobar_only": VARIANT_MFMA16P_W8 + 192 * 16,
+    "mfma16p_w8_x2": VARIANT_MFMA16P_W8 + 1024, "mfma16p_x2": VARIANT_MFMA16P + 1024,
+    "x_noexp": VARIANT_MFMA16X + 2048 * 1, "x_nosoftmax": VARIANT_MFMA16X + 2048 * 3,
+    "x_nolds": VARIANT_MFMA16X + 2048 * 4, "x_mfma_only": VARIANT_MFMA16X + 2048 * 7,
+    "x_nostage": VARIANT_MFMA16X + 2048 * 8, "x_bare": VARIANT_MFMA16X + 2048 * 15,
+    "x_nobar": VARIANT_MFMA16X + 2048 * 16, "x_noload": VARIANT_MFMA16X + 2048 * 32,
+    "x_nobar_noload": VARIANT_MFMA16X + 2048 * 48}
+if os.path.basename(LIB_PATH) in ("libfa2_hip_exp.so", "libfa2_hip_abl.so"):
+    VARIANTS.update(EXPERIMENTAL_VARIANTS)
 
 # Every symbol include/fa2_fwd.h declares (tests/test_abi.py checks the export list against the header).
 SYMBOLS = ("fa2_fwd", "fa2_fwd_variant", "fa2_query_tile", "fa2_query_tile_ex", "fa2_version", "fa2_last_error")

@@ -24,7 +24,12 @@ _lib = None
 
 
 def build(force=False):
-    """Compile fa2_oracle.c with gcc (seconds)."""
+    """Compile fa2_oracle.c with gcc (seconds).  FA2_ORACLE_LIB points the tests at another build of the same sources (the
+    sanitizer build of `make -C oracle asan`)."""
+    global _SO
+    if os.environ.get("FA2_ORACLE_LIB"):
+        _SO = os.environ["FA2_ORACLE_LIB"]
+        return _SO
     srcs = [os.path.join(_HERE, f) for f in ("fa2_oracle.c", "fa2_oracle_bwd.c")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libfa2_oracle.so"])

@@ -143,3 +143,18 @@ def test_static_tile_table():
     assert q(128, 37, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_GENERIC
     with pytest.raises(TypeError):
         q(128, 513, _lib.FA2_DTYPE_F32)
+
+
+def test_host_side_and_oracle_under_address_sanitizer():
+    """`make asan` (csrc/ and oracle/): the host side of the C-ABI library -- validation, strides, tile table, launchers' argument
+    packing -- and the oracle built with AddressSanitizer + UBSan, run under this file's CPU tests and the oracle's
+    (scripts/run_asan.sh).  CPU build only: GPU sanitizers are not available on the pool."""
+    import glob
+    if os.environ.get("FA2_HIP_LIB", "").endswith("_asan.so"):
+        pytest.skip("already inside the sanitizer run")
+    if not glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"):
+        pytest.skip("no clang AddressSanitizer run time here")
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",)}
+    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "run_asan.sh")], capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert " passed" in out.stdout and "failed" not in out.stdout

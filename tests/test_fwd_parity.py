@@ -570,11 +570,16 @@ def test_unsupported_variant_and_dtype_errors():
         fa.FlashAttention.apply(x.int(), x.int(), x.int())
     with pytest.raises(ValueError):
         fa.FlashAttention.apply(x, x[:, :, :16], x)
-    # experimental kernels are not in the product library (include/fa2_fwd.h lists what is): their ids are rejected
+    # experimental kernels are not in the product library (include/fa2_fwd.h lists what is): the product surface does not know
+    # their names, and the library rejects their ids
     y = torch.zeros(1, 1, 64, 128, device=DEV, dtype=torch.bfloat16)
     for name in ("mfma16p", "mfma16x", "mfma16s", "mfma8", "mfma8u", "abl_noexp"):
-        with pytest.raises(ValueError):
+        assert name not in _lib.VARIANTS and name in _lib.EXPERIMENTAL_VARIANTS
+        with pytest.raises(KeyError):
             fa.flash_attention_forward(y, y, y, DEV, variant=name)
+        O, L = torch.empty_like(y), torch.empty(1, 1, 64, 1, device=DEV, dtype=torch.bfloat16)
+        with pytest.raises(ValueError):
+            _lib.fa2_fwd(y, y, y, O, L, _lib.FA2_DTYPE_BF16, variant=_lib.EXPERIMENTAL_VARIANTS[name])
 
 
 def test_autograd_surface_backward_runs():
