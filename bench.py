@@ -48,6 +48,8 @@ CONFIGS = {  # BASELINE.json "configs"
     "n2048": dict(B=16, H=64, N=2048, d=128, dtype="bf16", causal=False),
     "c3_fp8": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=True),
     "c5_per_gpu": dict(B=16, H=8, N=16384, d=128, dtype="fp8", causal=False),   # BASELINE.json configs[4], one GPU's head shard
+    "fp8_4k": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=False),
+    "fp8_1k": dict(B=16, H=32, N=1024, d=128, dtype="fp8", causal=False),
 }
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "fp8": torch.float8_e4m3fn}
 # Dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (TFLOP/s)

@@ -26,25 +26,30 @@ os.environ["FA2_A64_DBG"] = hex(dbg.data_ptr())
 from flash_attention_dlrs_amd import flash_attention_forward  # noqa: E402
 
 torch.manual_seed(42)
-Q, K, V = (torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
 data = sys.argv[2] if len(sys.argv) > 2 else "randn"
+spread = 0.5 if c["dtype"] == "fp8" else 1.0        # (fp8 inputs as bench.py / benchmarks/variants.py draw them)
+Q, K, V = (torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev) * spread for _ in range(3))
+if data == "small":        # the usual 1/sqrt(d) softmax scale folded into Q (scores of unit variance: the deferred maximum never moves)
+    Q = Q * 128 ** -0.5 / spread ** 2
+Q, K, V = (t.to(TORCH_DTYPE[c["dtype"]]) for t in (Q, K, V))
 if data == "zeros":
     Q.zero_(); K.zero_(); V.zero_()
 elif data == "kzero":      # scores all zero, V random
     K.zero_()
 elif data == "vzero":
     V.zero_()
-elif data == "small":      # the usual 1/sqrt(d) softmax scale folded into Q
-    Q.mul_(128 ** -0.5)
+elif data == "small":
+    pass
 elif data == "ones":
     Q.fill_(0.1); K.fill_(0.1); V.fill_(1.0)
+VARIANT = os.environ.get("A64_STAMPS_VARIANT", "a64")     # "a8": the fp8 kernels (their stamped forms: FA2_A64_KERNEL=fa2_fwd_a8_...)
 for _ in range(20):
-    flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant="a64")
+    flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant=VARIANT)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(10):
-    flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant="a64")
+    flash_attention_forward(Q, K, V, dev, causal=c["causal"], variant=VARIANT)
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 10

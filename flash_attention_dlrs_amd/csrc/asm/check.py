@@ -23,6 +23,12 @@ from __future__ import annotations
 from .isa import Inst, TRANS_OPS
 
 
+def mfma_wait(ins: Inst) -> int:
+    """wait states between an MFMA and a reader / overwriter of its result (rules R1, R8): 12 for the 8-pass forms (and, on the
+    safe side, the 4-pass 16x16x32); the 16-pass v_mfma_f32_32x32x64_f8f6f4 holds its destination twice as long"""
+    return 20 if "32x32x64" in ins.op else 12
+
+
 def wait_states(ins: Inst) -> int:
     if ins.op in (".label", ".comment"):
         return 0
@@ -65,7 +71,9 @@ def fix(prog, max_rounds=64):
                                f"{prog[bad[0]].text().strip()} (keep scalar carry / compare sequences in one filler unit)")
         need = {}
         for idx, rule, _, dist in errs:
-            need[idx] = max(need.get(idx, 0), REQUIRED[rule.split()[0]] - dist)
+            key = rule.split()[0]
+            req = int(key.split("@")[1]) if "@" in key else REQUIRED[key]
+            need[idx] = max(need.get(idx, 0), req - dist)
         for idx in sorted(need, reverse=True):
             n = need[idx]
             added += n
@@ -102,13 +110,15 @@ def check_scc(prog):
     return errs
 
 
-def check_branch_targets(prog, need=12):
+def check_branch_targets(prog, need=None):
     """out-of-line blocks are scanned by check() where they stand in the listing, not where they are entered from: for every
     branch, the registers the target block touches before its first branch out must be `need` wait states clear of the last
     MFMA that wrote them on the path INTO the branch (rule R1 across a taken branch).
     Returns [(branch index, target label index, reg, missing wait states)]"""
     labels = {ins.ops[0].name: i for i, ins in enumerate(prog) if ins.op == ".label"}
     errs = []
+    if need is None:      # (the longest MFMA of the program decides: 20 wait states with a 16-pass MFMA in it, else 12)
+        need = max([mfma_wait(ins) for ins in prog if ins.is_mfma] or [12])
     for bi, br in enumerate(prog):
         if not (br.op.startswith("s_cbranch") or br.op == "s_branch"):
             continue
@@ -173,31 +183,31 @@ def check(prog, verbose=True):
             csrc = tuple(ins.ops[3].regs()) if hasattr(ins.ops[3], "regs") else ()
             for r in u:
                 if r in last_mfma_def:
-                    p, _, rng = last_mfma_def[r]
+                    p, pi, rng = last_mfma_def[r]
                     same_chain = (r in csrc) and rng == dst and csrc == dst
-                    if not same_chain and dist(p) < 12:
-                        errs.append((idx, "R1 mfma->mfma operand", r, dist(p)))
+                    if not same_chain and dist(p) < mfma_wait(prog[pi]):
+                        errs.append((idx, f"R1@{mfma_wait(prog[pi])} mfma->mfma operand", r, dist(p)))
                 if r in last_valu_def and dist(last_valu_def[r]) < 2:
                     errs.append((idx, "R2 valu->mfma", r, dist(last_valu_def[r])))
             for r in d:
                 if r in last_mfma_def:
-                    p, _, rng = last_mfma_def[r]
-                    if not (rng == dst and csrc == dst) and dist(p) < 12:
-                        errs.append((idx, "R1 mfma->mfma overwrite", r, dist(p)))
+                    p, pi, rng = last_mfma_def[r]
+                    if not (rng == dst and csrc == dst) and dist(p) < mfma_wait(prog[pi]):
+                        errs.append((idx, f"R1@{mfma_wait(prog[pi])} mfma->mfma overwrite", r, dist(p)))
             for r in csrc:
-                last_mfma_csrc[r] = here
+                last_mfma_csrc[r] = (here, mfma_wait(ins))
             for r in dst:
                 last_mfma_def[r] = (here, idx, dst)
                 last_valu_def.pop(r, None)
                 last_trans_def.pop(r, None)
         else:
             for r in list(u) + list(d):
-                if r in last_mfma_def and dist(last_mfma_def[r][0]) < 12:
-                    errs.append((idx, "R1 mfma result touched", r, dist(last_mfma_def[r][0])))
+                if r in last_mfma_def and dist(last_mfma_def[r][0]) < mfma_wait(prog[last_mfma_def[r][1]]):
+                    errs.append((idx, f"R1@{mfma_wait(prog[last_mfma_def[r][1]])} mfma result touched", r, dist(last_mfma_def[r][0])))
             if ins.is_valu:
                 for r in d:
-                    if r in last_mfma_csrc and dist(last_mfma_csrc[r]) < 12:
-                        errs.append((idx, "R8 mfma C overwritten", r, dist(last_mfma_csrc[r])))
+                    if r in last_mfma_csrc and dist(last_mfma_csrc[r][0]) < last_mfma_csrc[r][1]:
+                        errs.append((idx, f"R8@{last_mfma_csrc[r][1]} mfma C overwritten", r, dist(last_mfma_csrc[r][0])))
                     if r in last_wide_store and dist(last_wide_store[r]) < 2:
                         errs.append((idx, "R10 store data overwritten", r, dist(last_wide_store[r])))
                 if ins.op not in TRANS_OPS:

@@ -610,6 +610,74 @@ class Workgroup:
         hi = w.rd_f(i.ops[2]).astype(np.float16).view(np.uint16).astype(np.uint32)
         w.wr_v(i.ops[0], lo | (hi << 16))
 
+    # ---- fp8 (OCP e4m3fn / e5m2): conversions through torch (round to nearest even; e4m3fn has no infinities: values beyond
+    #      +-448 become NaN, as the hardware conversion gives without saturation -- the kernels keep P <= 2^6)
+    @staticmethod
+    def _f32_to_f8(x, bf8):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(torch.float8_e5m2 if bf8 else torch.float8_e4m3fn)
+        return t.view(torch.uint8).numpy().astype(np.uint32)
+
+    @staticmethod
+    def _f8_to_f32(u8, bf8):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(u8, np.uint8)).view(torch.float8_e5m2 if bf8 else torch.float8_e4m3fn).float().numpy()
+
+    def _cvt_pk_f8(self, w, i, bf8):
+        lo, hi = self._f32_to_f8(w.rd_f(i.ops[1]), bf8), self._f32_to_f8(w.rd_f(i.ops[2]), bf8)
+        pair = lo | (hi << 8)
+        old = w.rd_v(i.ops[0])
+        if tuple(i.mods.get("op_sel", (0, 0, 0)))[2]:
+            w.wr_v(i.ops[0], (old & np.uint32(0x0000FFFF)) | (pair << 16))
+        else:
+            w.wr_v(i.ops[0], (old & np.uint32(0xFFFF0000)) | pair)
+
+    def x_v_cvt_pk_fp8_f32(self, w, i):
+        self._cvt_pk_f8(w, i, False)
+
+    def x_v_cvt_pk_bf8_f32(self, w, i):
+        self._cvt_pk_f8(w, i, True)
+
+    def _f8_operand(self, w, o, bf8):
+        """8 registers of an f8f6f4 operand -> float64 [64 lanes][32 k slots] (slot j = byte j & 3 of register j >> 2)"""
+        regs = np.stack([w.rd_v(o, k) for k in range(8)], axis=1)            # [64][8] uint32
+        return self._f8_to_f32(regs.view(np.uint8).reshape(64, 32), bf8).astype(np.float64)
+
+    def x_v_mfma_f32_32x32x64_f8f6f4(self, w, i):
+        """A[m = l & 31][k = 32 (l >> 5) + j], B[k = 32 (l >> 5) + j][n = l & 31], j = byte index of the lane's 32-byte operand;
+        D as the 32x32 bf16 forms: row m = (r & 3) + 8 (r >> 2) + 4 (l >> 5), column n = l & 31.  cbsz / blgp: 0 = e4m3, 1 = e5m2"""
+        d, a, b, c = i.ops
+        fa, fb = self._f8_operand(w, a, i.mods.get("cbsz", 0) == 1), self._f8_operand(w, b, i.mods.get("blgp", 0) == 1)
+        assert i.mods.get("cbsz", 0) in (0, 1) and i.mods.get("blgp", 0) in (0, 1)
+        Am = np.concatenate([fa[:32], fa[32:]], axis=1)        # [32 rows][64 k]
+        Bm = np.concatenate([fb[:32], fb[32:]], axis=1)        # [32 cols][64 k]
+        Cm = np.zeros((32, 32), np.float64)
+        rows = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+        if isinstance(c, Reg):
+            for r in range(16):
+                x = w.rd_v(c, r).view(np.float32).astype(np.float64)
+                for h in range(2):
+                    Cm[rows(r, h), :] = x[32 * h:32 * h + 32]
+        Dm = (Am @ Bm.T + Cm).astype(np.float32)
+        for r in range(16):
+            w.wr_v(d, np.concatenate([Dm[rows(r, 0), :], Dm[rows(r, 1), :]]), r, masked=False)
+
+    def x_v_mfma_f32_16x16x128_f8f6f4(self, w, i):
+        """A[m = l & 15][k = 32 (l >> 4) + j], B[k = 32 (l >> 4) + j][n = l & 15]; D[m = 4 (l >> 4) + r][n = l & 15]"""
+        d, a, b, c = i.ops
+        fa, fb = self._f8_operand(w, a, i.mods.get("cbsz", 0) == 1), self._f8_operand(w, b, i.mods.get("blgp", 0) == 1)
+        Am = np.concatenate([fa[16 * g:16 * g + 16] for g in range(4)], axis=1)     # [16][128]
+        Bm = np.concatenate([fb[16 * g:16 * g + 16] for g in range(4)], axis=1)
+        Cm = np.zeros((16, 16), np.float64)
+        if isinstance(c, Reg):
+            for r in range(4):
+                x = w.rd_v(c, r).view(np.float32).astype(np.float64)
+                for g in range(4):
+                    Cm[4 * g + r, :] = x[16 * g:16 * g + 16]
+        Dm = (Am @ Bm.T + Cm).astype(np.float32)
+        for r in range(4):
+            w.wr_v(d, np.concatenate([Dm[4 * g + r, :] for g in range(4)]), r, masked=False)
+
     def x_v_permlane32_swap_b32(self, w, i):
         # lanes 32..63 of vdst swap with lanes 0..31 of src
         d, s = w.rd_v(i.ops[0]), w.rd_v(i.ops[1])
@@ -786,6 +854,21 @@ class Workgroup:
         data = out.view(np.uint32)  # [64][2]
         self._queue_vreg_write(w, w.lgkm_q, i.ops[0], data.T.copy())
 
+    def x_ds_read_b64_tr_b8(self, w, i):
+        """measured on the device (profiles/r01/ds_read_b64_tr_b8_lane_map.txt): in a 16-lane group lane i < 8 receives byte i of
+        the 8-byte segments addressed by lanes 0, 2, .., 14, lane i >= 8 byte i - 8 of those addressed by lanes 1, 3, .., 15"""
+        assert w.exec_mask().all(), "ds_read_b64_tr_b8 needs EXEC all ones"
+        addr = self._lds_addr(w, i, i.ops[1])
+        assert (addr % 8 == 0).all(), "ds_read_b64_tr_b8 misaligned"
+        self._bank_conflicts((i.tag or "ds_read_b64_tr_b8").split()[0], addr, 8, self.HALF_GROUPS)
+        raw = self._lds_read_lanes(addr, 8)      # [64][8]
+        out = np.zeros((64, 8), np.uint8)
+        for g in range(4):
+            for li in range(16):
+                for k in range(8):
+                    out[16 * g + li, k] = raw[16 * g + 2 * k + (li >> 3), li & 7]
+        self._queue_vreg_write(w, w.lgkm_q, i.ops[0], out.view(np.uint32).T.copy())
+
     def _lds_write(self, w, i, nbytes):
         addr = self._lds_addr(w, i, i.ops[0])
         assert (addr % min(nbytes, 8) == 0).all()
@@ -882,6 +965,9 @@ class Workgroup:
 
     def x_buffer_store_short(self, w, i):
         self._buf_store(w, i, 2)
+
+    def x_buffer_store_byte(self, w, i):
+        self._buf_store(w, i, 1)
 
     def x_global_store_dword(self, w, i):
         vaddr, src, sbase = i.ops

@@ -10,18 +10,30 @@ from .fa2_a64_gen import KARG_SIZE, Gen
 
 LOG2E = 1.4426950408889634
 # deferral threshold of the running maximum (log2 units) the launcher passes (fa2_a64.hip): P <= 2^thr; f16 P must stay below 65 504
-A64_THR = {"bf16": 60.0, "f16": 15.875}
+A64_THR = {"bf16": 60.0, "f16": 15.875, "e4m3": 6.0, "e5m2": 6.0}      # (fp8: fa2_mfma8x.hip's kThr, P <= 2^6)
+ESIZE = {"bf16": 2, "f16": 2, "e4m3": 1, "e5m2": 1}
+
+
+def _f8(dtype):
+    import torch
+    return torch.float8_e4m3fn if dtype == "e4m3" else torch.float8_e5m2
 
 
 def to_dt(x, dtype):
     if dtype == "bf16":
         return f32_to_bf16_rne(np.asarray(x, np.float32))
+    if dtype in ("e4m3", "e5m2"):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(_f8(dtype)).view(torch.uint8).numpy()
     return np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
 
 
 def from_dt(u16, dtype):
     if dtype == "bf16":
         return bf16_to_f32(u16)
+    if dtype in ("e4m3", "e5m2"):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(u16, np.uint8)).view(_f8(dtype)).float().numpy()
     return u16.view(np.float16).astype(np.float32)
 
 
@@ -51,8 +63,9 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     for nm, x in (("Q", Q), ("K", K), ("V", V)):
         arr = to_dt(x, dtype).view(np.uint8).reshape(-1).copy()
         bufs[nm] = (mem.alloc(arr), arr)
-    o_arr = np.full(B * H * N * D * 2, 0xAB, np.uint8)
-    l_arr = np.full(B * H * N * 2, 0xAB, np.uint8)
+    es = ESIZE[dtype]
+    o_arr = np.full(B * H * N * D * es, 0xAB, np.uint8)
+    l_arr = np.full(B * H * N * es, 0xAB, np.uint8)
     bufs["O"] = (mem.alloc(o_arr), o_arr)
     bufs["L"] = (mem.alloc(l_arr), l_arr)
     nq = (N + 255) // 256      # (N not a multiple of 256: the ragged kernels; the buffers hold exactly N rows)
@@ -61,11 +74,11 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     total = nunit * nbh
     assert causal or not pairs
     nwg = nwg or min(total, 256)
-    sb, sh, sn = H * N * D * 2, N * D * 2, D * 2
+    sb, sh, sn = H * N * D * es, N * D * es, D * es
     thr = A64_THR[dtype]
     if thr_override is not None:
         thr = thr_override
-    ka = pack_kargs([bufs[k][0] for k in "QKVOL"], (sb, sh) * 4 + (H * N * 2, N * 2), (sn,) * 4, N, H, nq, total,
+    ka = pack_kargs([bufs[k][0] for k in "QKVOL"], (sb, sh) * 4 + (H * N * es, N * es), (sn,) * 4, N, H, nq, total,
                     float(scale * LOG2E), thr, nunit, G, nbh, nwg, pow2=pow2, pairs=pairs)
     ka_arr = np.frombuffer(ka, np.uint8).copy()
     ka_addr = mem.alloc(ka_arr)
@@ -73,8 +86,9 @@ def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=No
     for wg in range(nwg):
         g = Workgroup(prog, mem, 4, wg, ka_addr)
         steps += g.run(order=order)
-    O = from_dt(o_arr.view(np.uint16), dtype).reshape(B, H, N, D)
-    L = from_dt(l_arr.view(np.uint16), dtype).reshape(B, H, N)
+    view = np.uint16 if es == 2 else np.uint8
+    O = from_dt(o_arr.view(view), dtype).reshape(B, H, N, D)
+    L = from_dt(l_arr.view(view), dtype).reshape(B, H, N)
     return O, L, steps
 
 

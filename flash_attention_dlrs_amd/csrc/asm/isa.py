@@ -108,11 +108,12 @@ def fmt_operand(o) -> str:
 
 
 # opcode classes (for the hazard checker and the issue-cost model)
-MFMA_OPS = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16"}
+MFMA_OPS = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16",
+            "v_mfma_f32_32x32x64_f8f6f4", "v_mfma_f32_16x16x128_f8f6f4"}
 TRANS_OPS = {"v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"}
-DS_OPS = {"ds_read_b128", "ds_read_b64_tr_b16", "ds_write_b64", "ds_read_b64", "ds_write_b128", "ds_read_b32", "ds_write_b32"}
+DS_OPS = {"ds_read_b128", "ds_read_b64_tr_b16", "ds_read_b64_tr_b8", "ds_write_b64", "ds_read_b64", "ds_write_b128", "ds_read_b32", "ds_write_b32"}
 VMEM_OPS = {"global_store_dwordx2", "buffer_load_dwordx4", "buffer_store_dwordx4", "buffer_store_short", "buffer_store_dword", "global_store_dword",
-            "global_store_dwordx4", "buffer_load_dword"}
+            "global_store_dwordx4", "buffer_load_dword", "buffer_store_byte"}
 SMEM_OPS = {"s_memrealtime", "s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16", "s_memtime"}
 
 
@@ -166,6 +167,12 @@ class Inst:
                         s += f" {k}"
                 elif k == "op_sel_hi":   # VOP3P: which half of each source feeds the HIGH result ([1,0]: src1's low word twice)
                     s += " op_sel_hi:[" + ",".join(str(int(x)) for x in v) + "]"
+                elif k == "op_sel":      # VOP3 (v_cvt_pk_fp8_f32: [0,0,1] = the HIGH half of the destination is written)
+                    if any(v):
+                        s += " op_sel:[" + ",".join(str(int(x)) for x in v) + "]"
+                elif k in ("cbsz", "blgp"):   # v_mfma_*_f8f6f4: the formats of A / B (0 = fp8 e4m3, 1 = bf8 e5m2)
+                    if v:
+                        s += f" {k}:{v}"
                 elif k == "off":  # global_* with no saddr
                     pass
                 else:
@@ -215,6 +222,8 @@ class Inst:
             return R(o[0]), R(o[1]) + R(o[2]) + R(o[3])
         if op == "v_readfirstlane_b32":
             return R(o[0]), R(o[1])
+        if op in ("v_cvt_pk_fp8_f32", "v_cvt_pk_bf8_f32"):
+            return R(o[0]), R(o[0]) + R(o[1]) + R(o[2])
         # generic: first operand is the destination
         if op.startswith("v_") or op.startswith("s_"):
             d = R(o[0])

@@ -13,7 +13,7 @@ from .fa2_a64_gen import module_text
 
 
 class MB:
-    def __init__(self, name, fillers, agpr_c=True, chain=False, mfma=True):
+    def __init__(self, name, fillers, agpr_c=True, chain=False, mfma=True, f8=False):
         self.name = name
         self.prog = []
         e = self.prog.append
@@ -57,7 +57,9 @@ class MB:
                 acc = A(0, 16) if agpr_c else V(0, 16)
             else:
                 acc = A(16 * u, 16) if agpr_c else V(16 * (u % 4), 16)
-            if mfma:
+            if mfma and f8:     # the 64-cycle fp8 form of the a8 kernel (operands of 8 registers)
+                e(I("v_mfma_f32_32x32x64_f8f6f4", acc, V(128 + 8 * (u % 4), 8), V(160 + 8 * (u % 4), 8), acc))
+            elif mfma:
                 e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
             for f in fillers(u):
                 if f.op.startswith("s_cbranch"):      # (the never-taken branch of the fire-test cases: a label of this kernel)
@@ -136,6 +138,22 @@ def cases():
     }
     for nm, pat in pats.items():
         out.append(MB(f"mb_{nm}", (lambda u, pat=pat: [f(u, k) for k, f in enumerate(pat)])))
+    # beside the 64-cycle fp8 MFMA (a8): unit costs and orderings of a run of the step's fillers (4 exp, 4 fma, 2 cvt, 2 max3, 1 read)
+    C8 = lambda u, k: I("v_cvt_pk_fp8_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), op_sel=(0, 0, k & 1))
+    C8D = lambda u, k: I("v_cvt_pk_fp8_f32", V(r(u, 0)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), op_sel=(0, 0, k & 1))   # same destination
+    TR8 = lambda u, k: I("ds_read_b64_tr_b8", V(64 + 2 * ((8 * u + k) % 16), 2), V(201), offset=512 * ((8 * u + k) % 32))
+    f8pats = {
+        "none": [], "e4": [EXP] * 4, "e8": [EXP] * 8, "e12": [EXP] * 12, "f8": [FMA] * 8, "f12": [FMA] * 12, "f16": [FMA] * 16,
+        "c4": [C8] * 4, "c8": [C8] * 8, "c12": [C8] * 12, "c8d": [C8D] * 8, "cb8": [CVT] * 8, "m8": [MX3] * 8, "m12": [MX3] * 12,
+        "t4": [TR8] * 4, "t8": [TR8] * 8,
+        "mix_il": [TR8, EXP, FMA, C8, MX3, EXP, FMA, EXP, FMA, C8, EXP, FMA, MX3],
+        "mix_grp": [TR8, EXP, EXP, EXP, EXP, FMA, FMA, FMA, FMA, C8, C8, MX3, MX3],
+        "mix_il_nocv": [TR8, EXP, FMA, MX3, EXP, FMA, EXP, FMA, EXP, FMA, MX3],
+        "mix_il_x2": [TR8, EXP, FMA, C8, MX3, EXP, FMA, EXP, FMA, C8, EXP, FMA, MX3] * 2,
+        "ef4": [EXP, FMA] * 4, "ef6": [EXP, FMA] * 6, "ef8": [EXP, FMA] * 8, "eff4": [EXP, FMA, FMA] * 4,
+    }
+    for nm, pat in f8pats.items():
+        out.append(MB(f"mb8_{nm}", (lambda u, pat=pat: [f(u, k) for k, f in enumerate(pat)]), f8=True))
     # no MFMA at all (the epilogue's regime): cycles per group of 8 instructions -> / 8 = cycles per instruction
     ACR = lambda u, k: I("v_accvgpr_read_b32", V(r(u, k)), A(16 * u + k))
     MUL = lambda u, k: I("v_mul_f32", V(r(u, k)), V(r(u, k)), V(203))

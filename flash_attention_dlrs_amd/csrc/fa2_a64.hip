@@ -40,6 +40,7 @@ struct DevState {
     bool ready = false, failed = false;
     hipModule_t mod = nullptr;
     hipFunction_t fn[2][2][2][2] = {};  // [a64 / a16][bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
+    hipFunction_t fn8[2] = {};          // a8: [e4m3 / e5m2], non-causal, N % 256 == 0
     int cus = 0;
 };
 DevState g_dev[kMaxDev];
@@ -79,6 +80,10 @@ DevState *dev_state() {
                     e = hipModuleGetFunction(&d.fn[m][t][c][r], d.mod, nm);
                     if (e != hipSuccess) d.fn[m][t][c][r] = nullptr;  // a kernel the generator did not emit: reported at launch
                 }
+    for (int t = 0; t < 2; ++t) {
+        e = hipModuleGetFunction(&d.fn8[t], d.mod, t ? "fa2_fwd_a8_e5m2_n" : "fa2_fwd_a8_e4m3_n");
+        if (e != hipSuccess) d.fn8[t] = nullptr;
+    }
     (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
     d.cus = fa2_device_cus();
     d.ready = true;
@@ -109,6 +114,28 @@ namespace {
 int launch(const Fa2Problem &p, int shape16);
 }
 
+// fp8: one byte per element, rows of 128 bytes; otherwise the conditions of the 16-bit kernels (16-byte aligned rows and bases,
+// N * row stride below 2 GiB); non-causal, N a multiple of 256 (every other fp8 shape: fa2_mfma8x.hip)
+bool fa2_a8_supports(const Fa2Problem &p) {
+    if (p.dtype != FA2_DTYPE_F8E4M3 && p.dtype != FA2_DTYPE_F8E5M2) return false;
+    if (p.d != 128 || p.N < 256 || (p.N & 255) || p.causal) return false;
+    if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
+    if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
+    const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
+    for (int k = 0; k < 4; ++k)
+        if (rows[k] < 128 || (rows[k] & 15) || (int64_t)(p.N + 512) * rows[k] >= (1LL << 31)) return false;
+    const uintptr_t ptrs[4] = {(uintptr_t)p.Q, (uintptr_t)p.K, (uintptr_t)p.V, (uintptr_t)p.O};
+    for (int k = 0; k < 4; ++k)
+        if (ptrs[k] & 15) return false;
+    if (((p.qs[0] | p.qs[1] | p.ks[0] | p.ks[1] | p.vs[0] | p.vs[1] | p.os[0] | p.os[1]) & 15) != 0) return false;
+    const int64_t nq = p.N / 256, jobs = (int64_t)p.B * p.H * nq;
+    if (jobs >= (1 << 22) || p.H >= (1 << 22) || p.ls[1] < p.N) return false;
+    return true;
+}
+int fa2_launch_a8(const Fa2Problem &p) { return launch(p, 2); }
+
+
+
 // The a16 kernels take what the a64 kernels take (same argument block, same job stream).
 bool fa2_a16_supports(const Fa2Problem &p) { return fa2_a64_supports(p); }
 int fa2_launch_a64(const Fa2Problem &p) { return launch(p, 0); }
@@ -116,25 +143,33 @@ int fa2_launch_a16(const Fa2Problem &p) { return launch(p, 1); }
 
 namespace {
 int launch(const Fa2Problem &p, int shape16) {
-    if (!fa2_a64_supports(p)) {
+    const bool f8 = shape16 == 2;
+    if (f8) {
+        if (!fa2_a8_supports(p)) {
+            fa2_set_error("a8 kernel: needs fp8 (e4m3fn / e5m2), d = 128, N a multiple of 256, no mask, unit d-stride, 16-byte aligned rows");
+            return FA2_ERR_UNSUPPORTED;
+        }
+    } else if (!fa2_a64_supports(p)) {
         fa2_set_error("a64 kernel: needs f16/bf16, d = 128, N >= 256, unit d-stride, 16-byte aligned rows, "
                       "scale > 0, N * row stride < 2 GiB");
         return FA2_ERR_UNSUPPORTED;
     }
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
-    hipFunction_t fn = d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
+    hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0]
+                          : d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {
-        fa2_set_error("%s kernel: this (dtype, causal, ragged N) form is not in the code object", shape16 ? "a16" : "a64");
+        fa2_set_error("%s kernel: this (dtype, causal, ragged N) form is not in the code object", f8 ? "a8" : shape16 ? "a16" : "a64");
         return FA2_ERR_UNSUPPORTED;
     }
     A64Args a;
     memset(&a, 0, sizeof(a));
     a.Q = p.Q; a.K = p.K; a.V = p.V; a.O = p.O; a.L = p.L;
-    a.qs_b = p.qs[0] * 2; a.qs_h = p.qs[1] * 2; a.ks_b = p.ks[0] * 2; a.ks_h = p.ks[1] * 2;
-    a.vs_b = p.vs[0] * 2; a.vs_h = p.vs[1] * 2; a.os_b = p.os[0] * 2; a.os_h = p.os[1] * 2;
-    a.ls_b = p.ls[0] * 2; a.ls_h = p.ls[1] * 2;
-    a.qs_n = (int32_t)(p.qs[2] * 2); a.ks_n = (int32_t)(p.ks[2] * 2); a.vs_n = (int32_t)(p.vs[2] * 2); a.os_n = (int32_t)(p.os[2] * 2);
+    const int es = f8 ? 1 : 2;    // bytes per element
+    a.qs_b = p.qs[0] * es; a.qs_h = p.qs[1] * es; a.ks_b = p.ks[0] * es; a.ks_h = p.ks[1] * es;
+    a.vs_b = p.vs[0] * es; a.vs_h = p.vs[1] * es; a.os_b = p.os[0] * es; a.os_h = p.os[1] * es;
+    a.ls_b = p.ls[0] * es; a.ls_h = p.ls[1] * es;
+    a.qs_n = (int32_t)(p.qs[2] * es); a.ks_n = (int32_t)(p.ks[2] * es); a.vs_n = (int32_t)(p.vs[2] * es); a.os_n = (int32_t)(p.os[2] * es);
     a.N = p.N; a.H = p.H; a.nq = (p.N + 255) / 256;
     a.nunit = p.causal ? (a.nq + 1) / 2 : a.nq;
     a.nbh = p.B * p.H;
@@ -146,6 +181,7 @@ int launch(const Fa2Problem &p, int shape16) {
     // 24 still fired a few times per job and wave -- measured 3 443 vs 2 946 cycles per tile step.  f16 P must stay below 65504.
     // (2^15.875 = 60 097 < 65 504; 12 -> 15.875: +3..4 % on the reference bench's fp16 shape, fewer rescales)
     a.thr = p.dtype == FA2_DTYPE_F16 ? 15.875f : 60.0f;
+    if (f8) a.thr = 6.0f;      // (P <= 2^6 stays far inside e4m3's 448; fa2_mfma8x.hip's kThr)
     a.group = 1;
     if (p.causal && (a.nbh & 7) == 0) {
         const int per_xcd = a.nbh / 8;
@@ -158,7 +194,7 @@ int launch(const Fa2Problem &p, int shape16) {
     // instead of each starting again at tile 0 at a time of its own.  The order is a function of (query block, nq) alone, so a
     // head's result does not depend on the launch it is part of (bit-identical head sharding).  Same-device A/B against
     // FA2_A64_PAIRS=0 (profiles/r03/pairs_ab.jsonl): c3 +1 %, N = 2048 +2.8 %, N >= 8192 0 .. -0.6 % (left alone there).
-    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && !shape16;
+    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && shape16 == 0;
 #ifdef FA2_A64_STAMPS
     down = false;      // (the diagnostic kernels use the registers for the debug pointer)
 #endif

@@ -122,6 +122,11 @@ int pick_variant(const Fa2Problem &p) {
         // shape (N = 4096), +4 % (N = 2048), +2.6 % (N = 8192), +2.5 % (N = 16384), +2.4 % (d = 64).
         return FA2_VARIANT_MFMA16H;
     }
+    // fp8, no mask, N a multiple of 256: the generated kernel A8 (asm/fa2_a8_gen.py: the A64 structure -- 4 waves x 64 rows, one wave
+    // per SIMD -- on v_mfma_f32_32x32x64_f8f6f4), bit-identical to MFMA8X.  Same-device A/B (benchmarks/variants.py,
+    // profiles/r03/a8_vs_mfma8x.jsonl): BASELINE configs[4]'s per-GPU shard (B16 H8 N16384) 2 266 vs 2 164 TFLOP/s (+4.7 %), B4 H32
+    // N4096 +1.4 .. 2.7 %, N = 1024 +-1 %: from N = 2048 on and at least a quarter of the CUs busy.
+    if (fa2_a8_supports(p) && p.N >= 2048 && (long long)(p.N / 256) * p.B * p.H >= T(64)) return FA2_VARIANT_A8;
     if (fa2_mfma8x_supports(p)) {
         // fp8: the double-rate k = 64 MFMA (64-key units).  Against MFMA8 (32x32x16 fp8, the bf16 rate) on MI355X:
         // +26 % at the c5 per-GPU shape (N = 16384 non-causal: 1 880 vs 1 492 TFLOP/s), +19 % at c3 causal.
@@ -173,6 +178,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_MFMA16H_W4: return fa2_launch_mfma16h(p, 4);
     case FA2_VARIANT_A64: return fa2_launch_a64(p);
     case FA2_VARIANT_A16: return fa2_launch_a16(p);
+    case FA2_VARIANT_A8: return fa2_launch_a8(p);
 #ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
     case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
@@ -315,6 +321,7 @@ int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_
 #endif
     case FA2_VARIANT_A64: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_A16: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
+    case FA2_VARIANT_A8: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
 #ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;

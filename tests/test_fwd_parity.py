@@ -398,6 +398,40 @@ def test_golden_fp8_e5m2_on_the_gpu(oracle):
 
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_generated_fp8_kernel_a8(oracle, dtype):
+    """the generated fp8 kernel (variant a8, asm/fa2_a8_gen.py: the a64 structure on v_mfma_f32_32x32x64_f8f6f4; non-causal, N a
+    multiple of 256): element by element against the oracle's deferred-maximum mode -- the bar of fa2_mfma8x below -- bit-identical
+    to fa2_mfma8x (same liberties, same order), several jobs per workgroup, (B, N, H, d)-strided inputs, and the table's choice"""
+    step = 0.25 if dtype == torch.float8_e5m2 else 0.125
+    u8 = lambda t: t.contiguous().view(torch.uint8)
+    for shape, seed in (((1, 2, 256, 128), 5), ((2, 3, 512, 128), 6), ((1, 5, 1024, 128), 7), ((3, 120, 768, 128), 8)):
+        Q, K, V = _rand(shape, dtype, seed=seed, spread=0.5)
+        O, L = hip_forward(Q, K, V, variant="a8")
+        O8, L8 = hip_forward(Q, K, V, variant="mfma8x")
+        assert torch.equal(u8(O), u8(O8)) and torch.equal(u8(L), u8(L8)), shape
+        if shape[0] * shape[1] <= 6:
+            f = lambda t: t.float().numpy()
+            O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=False, G=32, B_c=64, thr=6.0, sum_rounded=True)
+            O, L, O_ref, L_ref = O.float(), L.float().flatten(), torch.from_numpy(O_ref), torch.from_numpy(L_ref).flatten()
+            assert (O == O_ref).float().mean() >= 0.99 and (L == L_ref).float().mean() >= 0.97
+            assert ((O - O_ref).abs() <= step * O_ref.abs() + 0.5 * step * V.float().abs().max()).all()
+    gen = torch.Generator().manual_seed(9)
+    Q, K, V = ((torch.randn(2, 512, 3, 128, generator=gen) * 0.5).to(dtype).transpose(1, 2) for _ in range(3))     # row stride 3 * 128 bytes
+    O, L = hip_forward(Q, K, V, variant="a8")
+    O8, L8 = hip_forward(Q, K, V, variant="mfma8x")
+    assert torch.equal(u8(O), u8(O8)) and torch.equal(u8(L), u8(L8))
+    x = torch.zeros(1, 2, 320, 128).to(dtype)
+    with pytest.raises(TypeError):
+        hip_forward(x, x, x, variant="a8")                 # N not a multiple of 256
+    with pytest.raises(TypeError):
+        hip_forward(Q, K, V, causal=True, variant="a8")    # no causal form
+    en = fa.convert_triton_dtype(dtype)
+    assert _lib.query_tile(16384, 128, en, False, B=16, H=8)[0] == _lib.VARIANT_A8           # BASELINE.json configs[4], one GPU's shard
+    assert _lib.query_tile(16384, 128, en, True, B=16, H=8)[0] in (_lib.VARIANT_MFMA8X, _lib.VARIANT_MFMA8X_W4)
+    assert _lib.query_tile(16000, 128, en, False, B=16, H=8)[0] in (_lib.VARIANT_MFMA8X, _lib.VARIANT_MFMA8X_W4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("variant", ["mfma8x", "mfma8x_w4"])
 def test_fp8_mfma_kernel_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype, causal, variant):
