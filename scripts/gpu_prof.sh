@@ -4,7 +4,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROF_OUT:-prof}
 rm -rf $OUT && mkdir -p $OUT
 ARGS="${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline --no-extras}"
 echo "=== stats"

@@ -52,8 +52,8 @@ def main():
                 stats = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                          "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
                 break
-    out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc <group>] --output-format csv -- python3 bench.py "
-                      "--steps 20 --warmup 5 --no-cpu-baseline --no-extras  (scripts/gpu_prof.sh)",
+    out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc <group>] --output-format csv -- python3 bench.py " +
+                      os.environ.get("BENCH_ARGS", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras") + "  (scripts/gpu_prof.sh)",
            "workload": workload, "counters": counters, "kernel_ns_in_pmc_runs": kern_ns, "kernel_stats": stats}
     c = lambda k: counters.get(k, {}).get("mean_per_launch")
     if c("FETCH_SIZE") is not None and c("WRITE_SIZE") is not None:
