@@ -39,6 +39,10 @@ CONFIGS = {  # BASELINE.json "configs"
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
     "d64_long": dict(B=8, H=16, N=4096, d=64, dtype="fp16", causal=False),
     "d64_long_causal": dict(B=8, H=16, N=4096, d=64, dtype="bf16", causal=True),
+    "d64_8k": dict(B=4, H=16, N=8192, d=64, dtype="bf16", causal=False),
+    "d64_8k_causal": dict(B=4, H=16, N=8192, d=64, dtype="bf16", causal=True),
+    "d64_2k": dict(B=16, H=32, N=2048, d=64, dtype="bf16", causal=False),
+    "d64_2k_causal": dict(B=16, H=32, N=2048, d=64, dtype="bf16", causal=True),
     "n1024": dict(B=8, H=32, N=1024, d=128, dtype="bf16", causal=False),
     "causal_16k": dict(B=1, H=32, N=16384, d=128, dtype="bf16", causal=True),
     "causal_8k": dict(B=2, H=32, N=8192, d=128, dtype="bf16", causal=True),

@@ -22,11 +22,12 @@ VARIANT_MFMA16K_R2K4 = 23  # 21 / 22 are the experimental MFMA16P schedules
 VARIANT_A64 = 24
 VARIANT_A16 = 25
 VARIANT_A8 = 26
+VARIANT_A64D = 27
 # The variants include/fa2_fwd.h publishes -- what libfa2_hip.so runs.
 VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma16": VARIANT_MFMA16, "mfma16_w8": VARIANT_MFMA16_W8,
             "mfma32": VARIANT_MFMA32, "mfma16d": VARIANT_MFMA16D, "mfma16d_w4": VARIANT_MFMA16D_W4, "mfma16h": VARIANT_MFMA16H,
             "mfma16h_w4": VARIANT_MFMA16H_W4, "mfma8x": VARIANT_MFMA8X, "mfma8x_w4": VARIANT_MFMA8X_W4, "mfma16k": VARIANT_MFMA16K,
-            "mfma16k_r2k2": VARIANT_MFMA16K_R2K2, "mfma16k_r2k4": VARIANT_MFMA16K_R2K4, "a64": VARIANT_A64, "a16": VARIANT_A16, "a8": VARIANT_A8}
+            "mfma16k_r2k2": VARIANT_MFMA16K_R2K2, "mfma16k_r2k4": VARIANT_MFMA16K_R2K4, "a64": VARIANT_A64, "a16": VARIANT_A16, "a8": VARIANT_A8, "a64d": VARIANT_A64D}
 # Experimental kernels, A/B baselines and timing-only ablations: they exist only in the experiments / ablation builds of the library
 # (`make -C flash_attention_dlrs_amd/csrc experiments|abl`, csrc/fa2_experiments.h), which benchmarks/ load through FA2_HIP_LIB --
 # the names are published only when such a build is the one loaded.

@@ -27,8 +27,8 @@ _table = None
 
 # variants worth timing per dtype family (all covered by tests/test_fwd_parity.py)
 _CANDIDATES = {
-    "16": ("a64", "a16", "mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16_w8", "mfma16k", "mfma16k_r2k2", "mfma16k_r2k4"),
-    "8": ("mfma8x", "mfma8x_w4"),
+    "16": ("a64", "a16", "a64d", "mfma16d", "mfma16d_w4", "mfma16h", "mfma16h_w4", "mfma16_w8", "mfma16k", "mfma16k_r2k2", "mfma16k_r2k4"),
+    "8": ("mfma8x", "mfma8x_w4", "a8"),
 }
 
 

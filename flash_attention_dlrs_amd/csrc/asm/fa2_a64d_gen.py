@@ -1,91 +1,76 @@
 #!/usr/bin/env python3
-"""Generator of the gfx950 assembly kernels `fa2_fwd_a64_<dtype>_<c|n>` -- FA-2 forward, d = 128, f16 / bf16.
+"""Generator of the gfx950 assembly kernels `fa2_fwd_a64d_<dtype>_<c|n>` -- FA-2 forward, HEAD SIZE 64, f16 / bf16: the a64 kernel
+(fa2_a64_gen.py: 4 waves x 64 query rows, one wave per SIMD, persistent grid, continuous tile stream, LDS-DMA staging,
+modulo-scheduled softmax, causal split row map) at d = 64.  The reference runs every power-of-two head size through one kernel
+(/root/reference/src/flash_attention_kernels.py:17-32); here d = 64 ran on the 8-wave HIP kernels at 32-37 % of the matrix peak.
 
-Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108 (exp2-domain online softmax in fp32, P rounded
-RTNE to the I/O dtype before P.V, O /= l once at the end, L = m + log2 l), as in fa2_mfma16h.hip.
-
-Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent structure"):
-  * workgroup = 4 waves = one 256-row Q block; a wave owns two 32-row query blocks (qb = 0, 1) and the WHOLE 512-entry
-    register file: O^T in a[0:127], Q in a[128:191], the V^T fragments in a[192:255]; two score buffers, the current
-    K tile and the softmax state in the arch VGPRs;
-  * swapped products: S^T[key][query] = K.Q^T, O^T[d][query] += V^T.P^T on v_mfma_f32_32x32x16 -- a lane owns one query
-    row per query block, P never leaves the registers (the S accumulator, packed in place, is the B operand of P.V);
-  * 64-key K/V tiles arrive by LDS-DMA (buffer_load ... lds) into rings of FOUR K and four V buffers; LDS image = 8-row x
-    32-column subtiles of 512 B with the 16-byte slots XOR-swizzled (T10 image (a)): row reads (ds_read_b128) and
-    transposed reads (ds_read_b64_tr_b16) are conflict-free and need two per-lane base registers each, the rest is an
-    immediate;
-  * per tile t two phases of 32 MFMAs:  A(t) = QK^T(t+1) || finish-softmax(t) (exp2, row sums, cvt) || V(t) tr-reads
-                                        B(t) = P.V(t)    || start-softmax(t+1) (row max, decision, s*c - m) || K(t+2) reads
-                                                         || LDS-DMA of V(t+3), K(t+4)
-    ONE barrier per tile (between A and B) behind a COUNTED `s_waitcnt vmcnt(8)`: a tile's DMA pieces have two tile steps
-    to land.  The loop body is four tiles (buffer indices and score-buffer parity are immediates);
-  * the tile stream is CONTINUOUS across jobs: every job has a multiple of four tiles, and its last body (the "seam")
-    already streams the next job's K(0..3), V(0..2) and Q rows and computes its first QK^T; only the epilogue (O through
-    the wave's LDS slice, L) sits between two jobs;
-  * persistent grid: a workgroup walks its jobs (non-causal: one Q block; causal: the pair (nq-1-u, u)).
-
-The instruction stream is built as isa.Inst objects: printed to a .s file for the assembler, checked by check.py (wait
-states) and executed by emu.py in the CPU test-suite (tests/test_asm_emu.py) against an fp64 reference.
+Half the columns: a 64-key step is 16 + 16 MFMAs of v_mfma_f32_32x32x16 (and the eight 16x16x32 row sums) against the same 64 x 64
+scores of softmax -- the kernel is VALU-issue bound (~1 350 cycles of softmax per 1 150 of MFMA); its MFMA lists keep a64's 32 + 40
+slots with an MFMA in every second product slot, and emit_phase hands each MFMA the fillers of the slots it stands for (later
+runs take over what an earlier one has too much of).  Score layout, packed P, row sums, masks and rescale are a64's; rows are 128
+bytes, so the tile images (8 KiB), the DMA pieces (two per wave and tile), the Q staging and the epilogue have the geometry of the
+fp8 kernel (fa2_a8_gen.py).  N a multiple of 256.
 """
 from __future__ import annotations
 
-import argparse
 import sys
 
 from .isa import A, EXEC, I, Inst, Label, M0, Reg, S, V, VCC, comment, label, waitcnt
 
 # ------------------------------------------------------------------------------------------------- register map
 # arch VGPRs
-SBUF = (0, 64)            # two score buffers of 64 registers: group g = 2*qb + kb at +16 g
-VF = 128                  # V^T fragments: (kstep, db) at VF + 4 * (4 * kstep + db)
-V_KRE, V_KRO = 192, 193   # K row-read lane bases (even / odd k-step)
-V_VR0, V_VR1 = 194, 195   # V transposed-read lane bases (u = 0 / 1), the V ring's LDS offset included
-V_DKO, V_DVO = 196, 197   # LDS-DMA per-lane source offsets (K / V row stride)
-V_MC = (198, 199)         # running row maximum in the exp2 domain (c * max), per query block
-V_RS = ((200, 201), (202, 203))  # (unused: the row sums live in V_LACC)
-V_MX = ((204, 205), (206, 207))  # row-max chains [qb][kb]
-V_CO = (208, 209)         # rescale coefficient per query block
-V_T = tuple(range(210, 220))     # temporaries (V_T[2] = v212 is 4-aligned: a zero MFMA operand in the epilogue)
-V_QOFF = 220              # (unused)
-V_LANE = 221
-V_EW = 222                # epilogue LDS write base (row i, +8h)
-V_ESW = 223               # (unused)
-V_ER = 224                # epilogue LDS read base
-V_EO = 225                # epilogue global store lane offset (os_n)
-V_L2 = 226                # L store lane offset
-V_ST_LAST, V_ST_ACC = 227, 228   # diagnostic builds: last stamp (low word), accumulators [3] (228..230)
-V_NINF = 231              # causal: -inf (a literal would be the second constant-bus operand beside VCC)
+SBUF = (0, 64)            # two score buffers of 64 registers: group g = 2*qb + kb at +16 g (packed in place: P(qb, kstep = 2 kb + s) at + 4 s)
+KF = 128                  # K fragments of the next tile: (kb, ks) at KF + 4 (4 kb + ks), ks = 0..3
+V_KR = (160, 161, 162, 163)   # K row-read lane bases per 16-column step ks: chunk 2 ks + h
+V_VR = (164, 165)         # V transposed-read lane bases per 32-column block db (the V ring's LDS offset included)
+V_QR = (168, 169, 170, 171)   # Q row-read lane bases in the wave's slice
+V_DKO, V_DVO = 172, 173   # LDS-DMA per-lane source offsets of K / V rows
+V_DQ = (174, 175)         # ... of Q rows (even / odd 8-row group)
+V_MC = (176, 177)         # running row maximum in the exp2 domain (c * max), per query block
+V_CO = (178, 179)         # rescale coefficient per query block
+V_MX = ((180, 181), (182, 183))  # row-max chains [qb][kb]
+V_MSV = (184, 185)        # running maximum of the finished job
+V_LANE = 186
+V_EW, V_ER, V_EO, V_L2 = 187, 188, 189, 190   # epilogue: LDS write base, LDS read base, global store lane offset, L store lane offset
+V_IMH = 191               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
+V_T = tuple(range(192, 202))     # temporaries (V_T[0], [2], .. even)
+V_Z = 204                 # 4 registers, 4-aligned: the zero operand of the epilogue's clearing MFMAs
+V_ONES = 208              # 4 registers: the 0 / 1 A operand of the row-sum MFMA (v_mfma_f32_16x16x32)
+V_LACC = (216, 220)       # row-sum accumulators of the two query blocks (4 registers each; register 0 = the lane's own row)
+V_ST_LAST, V_ST_ACC = 224, 225   # diagnostic builds: last stamp (low word), accumulators [3]
+V_NINF = 231
 NINF = V(V_NINF)
-V_DKO2, V_DVO2 = 232, 233  # V_DKO / V_DVO + 128 (second half of an 8-row piece)
-V_LSV = (234, 235)        # [0]: read-back address of the epilogue; [1] = V_PM[5] in the causal kernels
-V_MSV = (236, 237)        # running maximum of the finished job
-V_ONES = 244              # 4 registers: the 0 / 1 A operand of the row-sum MFMA (v_mfma_f32_16x16x32)
-V_LACC = (248, 252)       # row-sum accumulators of the two query blocks (4 registers each; register 0 = the lane's own row)
-V_DQE, V_DQO = 240, 241   # LDS-DMA per-lane source offsets of the Q rows (row stride qs_n; even / odd 8-row group)
-V_QRE, V_QRO = 242, 243   # Q row-read lane bases in the wave's slice (even / odd k-step)
-V_IMH = 238               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
-V_PM = (200, 201, 202, 203, 220, 235, 221, 239)   # causal: AND masks of the eight packed P registers of a triangle group (221 =
-#                           V_LANE, dead after the set-up)
+V_LSV = (232, 233)
+V_PM = (236, 237, 238, 239, 240, 241, 242, 243)   # causal: AND masks of the eight packed P registers of a triangle group
 
 
 # AGPRs
 def A_O(qb, db):
-    return A((qb * 4 + db) * 16, 16)
+    return A((qb * 2 + db) * 16, 16)
 
 
 def A_Q(qb, ks):
-    return A(128 + (qb * 8 + ks) * 4, 4)
+    return A(64 + (qb * 4 + ks) * 4, 4)
 
 
 def A_K(kb, ks):
-    # the K tile lives in ARCH VGPRs v[128:191]: ds_read into accumulator registers while MFMAs write accumulators was
-    # measured 470 cycles per tile slower (and skews the four waves at the barrier)
-    return V(VF + (kb * 8 + ks) * 4, 4)
+    return V(KF + (kb * 4 + ks) * 4, 4)
 
 
 def V_F(kstep, db):
-    # V^T fragments in a[192:255]: read in phase A, whose MFMAs (QK^T) write arch VGPRs
-    return A(192 + 4 * (4 * kstep + db), 4)
+    # V^T fragments in a[96:127]: read in phase A, whose MFMAs (QK^T) write arch VGPRs
+    return A(96 + 4 * (2 * kstep + db), 4)
+
+
+def swz_k(row):
+    """K / Q tile image: 16-byte chunk c of row r at 128 r + 16 (c ^ swz_k(r)) (fa2_mfma8x.hip's, conflict-free for the row reads)"""
+    return (((row >> 1) & 1) << 2) | ((row >> 2) & 3)
+
+
+def swz_v(row):
+    """V tile image: 16-byte chunk c of row r at 128 r + 16 (c ^ swz_v(r)): rows two apart swap the two 32-column blocks, so the 4 x 4
+    rows x chunks of a transposing read fall on 32 different 8-byte bank slots"""
+    return ((row >> 1) & 1) << 2
 
 
 # SGPRs.  s4..s47 hold the kernel arguments (loaded once).
@@ -119,13 +104,14 @@ S_FIRE = (S(0, 2), S(2, 2))      # per query block: lanes whose row maximum pass
 S_X2 = S(82)
 
 # LDS map (bytes)
-KB = (0, 16384)
-VBASE = 32768
-VB = (0, 16384)                  # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
-EPI = 65536                      # + 16384 * wave: the wave's private 64 x 256-byte slice: the next job's Q rows land here by
-                                 # LDS-DMA (K-tile image) on their way to a[128:191]; later the job's O rows leave through it
-EPI_ROW = 272                    # (= 256 + 16, formed with shifts in k_setup) byte stride of an O row in the slice during the epilogue (k_setup)
-LDS_TOTAL = 131072
+KB = (0, 8192)
+VBASE = 16384
+VB = (0, 8192)                   # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
+EPI = 32768                      # + 16384 * wave: the wave's private slice: the next job's 64 Q rows land here by LDS-DMA (8 KiB,
+                                 # K-tile image) on their way to a[128:159]; later the job's O rows leave through it
+EPI_ROW = 136                    # (= 128 + 8) byte stride of an O row in the slice during the epilogue: 8-byte aligned for the
+                                 # row read-back, the 4-byte column writes of 32 lanes are 2-way (free for ds_write_b32)
+LDS_TOTAL = 32768 + 4 * 16384
 
 KARG_SIZE = 192
 NSLOT = 24
@@ -134,10 +120,10 @@ NSLOT = 24
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
                  caps=(5, 24), split=True):
-        assert dtype in ("bf16", "f16")
+        assert dtype in ("bf16", "f16") and not ragged, "a64d: f16 / bf16, N a multiple of 256"
         self.dtype = dtype
         self.causal = causal
-        self.name = name or f"fa2_fwd_a64_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
+        self.name = name or f"fa2_fwd_a64d_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
         self.atmp = 0          # (ragged) which of the two address temporaries the next buffer operation takes
         self.atmp_regs = (V_T[8], V_T[9])
         self.prog: list[Inst] = []
@@ -158,7 +144,7 @@ class Gen:
         self.abl = set(abl)    # timing-only ablations of the steady loop (diagnostic builds; results wrong by construction)
         self.R, self.dk, self.dv = ring   # ring depth; K(t + dk) and V(t + dv) are streamed in phase B(t): dk <= R + 1, dv <= R
         assert 3 <= self.dk <= min(self.R + 1, 4) and 2 <= self.dv <= self.R and 4 % self.R == 0
-        self.vm = 8 * min(self.dk - 3, self.dv - 2)  # DMA pieces that may stay in flight across the mid-step barrier
+        self.vm = 4 * min(self.dk - 3, self.dv - 2)  # DMA pieces that may stay in flight across the mid-step barrier
         self._cache = {}
         self.stamps = stamps   # diagnostic build: s_memtime stamps of the job timeline go to the debug buffer
         # Causal, the LIGHT job of a unit walks DOWNWARDS (the host sets bit 25 of the decode word): a unit is the heavy job
@@ -307,69 +293,64 @@ class Gen:
           I("s_load_dwordx2", S_DBG, S_KARG, 176), I("s_load_dword", S_LG, S_KARG, 184))
         lane, t0, t1, t2, t3 = V(V_LANE), V(V_T[0]), V(V_T[1]), V(V_T[2]), V(V_T[3])
         e(I("v_and_b32", lane, 63, V(0)), I("v_lshrrev_b32", t0, 6, V(0)), I("s_nop", 1), I("v_readfirstlane_b32", S_WAVE, t0), I("s_nop", 4),
-          I("s_lshl_b32", S_LDSW, S_WAVE, 11))
+          I("s_lshl_b32", S_LDSW, S_WAVE, 10))
         # i = lane & 31, h = lane >> 5
-        # ---- K row-read bases: 2048 (i >> 3) + 64 (i & 7) + 16 ((2 e + h) ^ ((i >> 2) & 3))
+        # ---- K row-read bases: row i, chunk c = 4 ks + 2 u + h at 128 i + 16 (c ^ swz_k(i)), swz_k(i) = 4 ((i >> 1) & 1) | ((i >> 2) & 3)
         e(comment("K row-read lane bases"),
           I("v_and_b32", t0, 31, lane),                    # i
-          I("v_lshrrev_b32", t1, 3, t0), I("v_lshlrev_b32", t1, 11, t1),   # 2048 (i >> 3)
-          I("v_and_b32", t2, 7, t0), I("v_lshl_add_u32", t1, t2, 6, t1),   # + 64 (i & 7)
-          I("v_bfe_u32", t2, t0, 2, 2),                    # g = (i >> 2) & 3
-          I("v_lshrrev_b32", t3, 5, lane),                 # h
-          I("v_xor_b32", t2, t2, t3),                      # h ^ g          (even k-step: chunk slot (0 + h) ^ g)
-          I("v_lshl_add_u32", V(V_KRE), t2, 4, t1),
-          I("v_xor_b32", t2, 2, t2),                       # (2 + h) ^ g
-          I("v_lshl_add_u32", V(V_KRO), t2, 4, t1))
-        # ---- V transposed-read bases: VBASE + 64 (4 h + q) + 16 ((2 w + (p >> 1)) ^ ((2 u + h) & 3)) + 8 (p & 1)
-        #      w = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3
+          I("v_bfe_u32", t1, t0, 1, 1), I("v_lshlrev_b32", t1, 2, t1),
+          I("v_bfe_u32", t2, t0, 2, 2), I("v_or_b32", t1, t1, t2),          # swz_k(i)
+          I("v_lshrrev_b32", t2, 5, lane), I("v_xor_b32", t1, t1, t2),      # h ^ swz_k(i)
+          I("v_lshlrev_b32", t3, 7, t0))                   # 128 i
+        for ks in range(4):     # chunk 2 ks + h
+            e(I("v_xor_b32", t2, 2 * ks, t1), I("v_lshl_add_u32", V(V_KR[ks]), t2, 4, t3))
+        # ---- V transposed-read bases (ds_read_b64_tr_b16): in a 16-lane group lane 4 q + p supplies key row 4 h + q, columns
+        #      16 w + 4 p .. + 3 of the 32-column block db (w = (lane >> 4) & 1):
+        #      VBASE + 128 (4 h + q) + 16 ((4 db + 2 w + (p >> 1)) ^ swz_v(row)) + 8 (p & 1),  swz_v(row) = 4 ((q >> 1) & 1)
         e(comment("V transposed-read lane bases"),
           I("v_bfe_u32", t0, lane, 2, 2),                  # q
-          I("v_lshrrev_b32", t3, 5, lane),                 # h
-          I("v_lshl_add_u32", t0, t3, 2, t0),              # 4 h + q
-          I("v_lshlrev_b32", t0, 6, t0),                   # 64 (4 h + q)
-          I("v_and_b32", t1, 1, lane), I("v_lshl_add_u32", t0, t1, 3, t0),  # + 8 (p & 1)
-          I("v_add_u32", t0, VBASE, t0),
-          I("v_bfe_u32", t1, lane, 4, 1), I("v_lshlrev_b32", t1, 1, t1),    # 2 w
-          I("v_bfe_u32", t2, lane, 1, 1), I("v_or_b32", t1, t1, t2),        # 2 w + (p >> 1)
-          I("v_xor_b32", t2, t1, t3),                      # u = 0: ^ h
-          I("v_lshl_add_u32", V(V_VR0), t2, 4, t0),
-          I("v_xor_b32", t2, 2, t2),                       # u = 1: ^ (2 + h)
-          I("v_lshl_add_u32", V(V_VR1), t2, 4, t0))
-        # ---- LDS-DMA lane source offsets: l' = lane & 31: row_in = l' >> 2, slot = l' & 3, sub = lane >> 5
-        #      chunk = 4 sub + (slot ^ (2 (wave & 1) + (l' >> 4)));  offset = row_in * stride + 16 chunk
+          I("v_lshrrev_b32", t1, 5, lane), I("v_lshl_add_u32", t1, t1, 2, t0),          # 4 h + q
+          I("v_lshlrev_b32", t1, 7, t1),                   # 128 row
+          I("v_and_b32", t2, 1, lane), I("v_lshl_add_u32", t1, t2, 3, t1),              # + 8 (p & 1)
+          I("v_add_u32", t1, VBASE, t1),
+          I("v_bfe_u32", t2, lane, 4, 1), I("v_lshlrev_b32", t2, 1, t2),                # 2 w
+          I("v_bfe_u32", t3, lane, 1, 1), I("v_or_b32", t2, t2, t3),                    # + (p >> 1)
+          I("v_bfe_u32", t3, t0, 1, 1), I("v_lshlrev_b32", t3, 2, t3), I("v_xor_b32", t2, t2, t3))   # ^ swz_v
+        for db in range(2):
+            e(I("v_xor_b32", t3, 4 * db, t2), I("v_lshl_add_u32", V(V_VR[db]), t3, 4, t1))
+        # ---- LDS-DMA lane source offsets: a piece is 8 rows x 128 bytes (rows 8 R ..); lane i lands at row 8 R + (i >> 3), 16-byte
+        #      position i & 7 of the image, which holds chunk (i & 7) ^ swz_k(row) (K / Q) or (i & 7) ^ swz_v(row) (V).  Bit 3 of the row
+        #      (swz_k only) is R & 1: the wave's parity for K (R = wave, wave + 4)
         e(comment("LDS-DMA per-lane source offsets"),
-          I("v_and_b32", t0, 3, lane),                     # slot
-          I("v_bfe_u32", t1, lane, 4, 1),                  # l' >> 4
-          I("s_and_b32", S_T[0], S_WAVE, 1), I("s_lshl_b32", S_T[0], S_T[0], 1),
-          I("v_or_b32", t1, S_T[0], t1),
-          I("v_xor_b32", t0, t0, t1),
-          I("v_lshrrev_b32", t1, 5, lane), I("v_lshl_or_b32", t0, t1, 2, t0),   # 4 sub + ...
-          I("v_lshlrev_b32", t0, 4, t0),                   # 16 chunk
-          I("v_bfe_u32", t1, lane, 2, 3))                  # row_in
+          I("v_lshrrev_b32", t1, 3, lane),                 # row_in
+          I("v_and_b32", t0, 7, lane))                     # pos
         e(waitcnt(lgkmcnt=0, comment="kernel arguments are in"))
-        e(I("v_mul_lo_u32", t2, t1, S_KSN), I("v_add_u32", V(V_DKO), t2, t0), I("v_add_u32", V(V_DKO2), 128, V(V_DKO)),
-          I("v_mul_lo_u32", t2, t1, S_VSN), I("v_add_u32", V(V_DVO), t2, t0), I("v_add_u32", V(V_DVO2), 128, V(V_DVO)))
-        # ---- Q rows: the same piece shape for the 8-row groups R = 0..7 of the wave's 64 rows; the slot XOR is 2 (R & 1) + (l' >> 4)
-        e(comment("Q staging: LDS-DMA lane offsets (even / odd row group) and row-read bases in the wave's slice"),
-          I("v_and_b32", t0, 3, lane), I("v_bfe_u32", t2, lane, 4, 1),
-          I("v_xor_b32", t3, t0, t2),                       # even R: slot ^ (l' >> 4)
-          I("v_lshrrev_b32", t2, 5, lane), I("v_lshl_or_b32", t3, t2, 2, t3), I("v_lshlrev_b32", t3, 4, t3),
-          I("v_mul_lo_u32", t2, t1, S_QSN), I("v_add_u32", V(V_DQE), t2, t3),
-          I("v_xor_b32", t3, 32, t3),                       # odd R: slot ^ (2 + (l' >> 4)): bit 1 of the slot = bit 5 of 16 * chunk
-          I("v_add_u32", V(V_DQO), t2, t3),
-          I("s_lshl_b32", S_T[0], S_WAVE, 14), I("s_add_u32", S_T[0], S_T[0], EPI),
-          I("v_add_u32", V(V_QRE), S_T[0], V(V_KRE)), I("v_add_u32", V(V_QRO), S_T[0], V(V_KRO)))
-        # ---- epilogue: the wave's slice holds a query block's 32 O rows at a stride of EPI_ROW = 272 bytes (256 + 16: the
-        #      8-byte writes of a column group and the 16-byte row reads both spread over all banks, and every address is a lane
-        #      base plus an immediate).  Write base EPI + 16384 wave + 272 i + 8 h
+        e(I("s_and_b32", S_T[0], S_WAVE, 1))               # R & 1 for the K / V pieces
+        # swz_k(row) = 4 ((row_in >> 1) & 1) | (((row_in >> 2) & 1) + 2 (R & 1))
+        def swz_k_ops(dst, par):
+            out = [I("v_bfe_u32", t2, t1, 1, 1), I("v_lshlrev_b32", t2, 2, t2), I("v_bfe_u32", t3, t1, 2, 1), I("v_or_b32", t2, t2, t3)]
+            if isinstance(par, Reg):
+                out += [I("s_lshl_b32", S_T[1], par, 1), I("v_or_b32", t2, S_T[1], t2)]
+            elif par:
+                out += [I("v_or_b32", t2, 2, t2)]
+            return out + [I("v_xor_b32", t2, t2, t0), I("v_lshlrev_b32", dst, 4, t2)]       # 16 (pos ^ swz_k)
+        e(swz_k_ops(t2, S_T[0]), I("v_mul_lo_u32", t3, t1, S_KSN), I("v_add_u32", V(V_DKO), t3, t2))
+        for par in range(2):
+            e(swz_k_ops(t2, par), I("v_mul_lo_u32", t3, t1, S_QSN), I("v_add_u32", V(V_DQ[par]), t3, t2))
+        # swz_v(row) = 4 ((row_in >> 1) & 1)
+        e(I("v_bfe_u32", t2, t1, 1, 1), I("v_lshlrev_b32", t2, 2, t2), I("v_xor_b32", t2, t2, t0), I("v_lshlrev_b32", t2, 4, t2),
+          I("v_mul_lo_u32", t3, t1, S_VSN), I("v_add_u32", V(V_DVO), t3, t2))
+        e(comment("Q row-read bases in the wave's slice"),
+          I("s_lshl_b32", S_T[0], S_WAVE, 14), I("s_add_u32", S_T[0], S_T[0], EPI))
+        e([I("v_add_u32", V(V_QR[k]), S_T[0], V(V_KR[k])) for k in range(4)])
+        # ---- epilogue: the wave's slice holds a query block's 32 O rows (64 columns: 128 bytes) at a stride of EPI_ROW = 136 bytes.
+        #      Write base (row i, + 8 h): slice + 136 i + 8 h;  read-back (a = lane >> 3, ec = lane & 7): slice + 136 a + 16 ec
+        #      (+ 8 x 136 k: row 8 k + a), two ds_read_b64; store offset a * os_n + 16 ec
         e(comment("epilogue lane constants"),
           I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane),
-          I("v_lshlrev_b32", t1, 8, t0), I("v_lshl_add_u32", t1, t0, 4, t1),    # 272 i
-          I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1))
-        # read-back: a = lane >> 4, ec = lane & 15: base + 272 a + 16 ec (+ 4 x 272 k: row 4 k + a); store offset a * os_n + 16 ec
-        e(I("v_lshrrev_b32", t0, 4, lane), I("v_and_b32", t1, 15, lane),
-          I("v_lshlrev_b32", t2, 8, t0), I("v_lshl_add_u32", t2, t0, 4, t2),    # 272 a
-          I("v_lshl_add_u32", t2, t1, 4, t2), I("v_add_u32", V(V_ER), S_T[0], t2),
+          I("v_mul_u32_u24", t1, EPI_ROW, t0), I("v_lshl_add_u32", t1, t3, 3, t1), I("v_add_u32", V(V_EW), S_T[0], t1),
+          I("v_lshrrev_b32", t0, 3, lane), I("v_and_b32", t1, 7, lane),
+          I("v_mul_u32_u24", t2, EPI_ROW, t0), I("v_lshl_add_u32", t2, t1, 4, t2), I("v_add_u32", V(V_ER), S_T[0], t2),
           I("v_mul_lo_u32", t2, t0, S_OSN), I("v_lshl_add_u32", V(V_EO), t1, 4, t2),
           I("v_and_b32", t0, 31, lane), I("v_lshlrev_b32", V(V_L2), 1, t0))
         if self.stamps:
@@ -391,10 +372,6 @@ class Gen:
           I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
           I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
-        if self.ragged and not self.causal:
-            e(comment("ragged, non-causal: real keys in a job's last 256; -inf"),
-              I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
-              I("v_mov_b32", NINF, float("-inf")))
         if self.causal:
             e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
@@ -493,19 +470,19 @@ class Gen:
 
     # ------------------------------------------------------------------ LDS-DMA
     def dma_piece(self, which, piece, buf):
-        """one 1-KiB LDS-DMA piece of the next K / V tile into ring buffer `buf`.  piece j: rows 8 R .. 8 R + 7 with
-        R = wave (j < 2) or wave + 4, 128-byte half j & 1 (the +128 rides in the second lane-offset register)"""
+        """one 1-KiB LDS-DMA piece of the next K / V tile into ring buffer `buf`: piece j = rows 8 R .. 8 R + 7 (whole 128-byte rows)
+        with R = wave + 4 j, at 1024 R of the tile image"""
         if which == "k":
-            rsrc, vl, vl2, base, s32, lds0 = S_KRS, V(V_DKO), V(V_DKO2), S_KDMA, S_K32, KB[buf]
+            rsrc, vl, base, s32, lds0 = S_KRS, V(V_DKO), S_KDMA, S_K32, KB[buf]
         else:
-            rsrc, vl, vl2, base, s32, lds0 = S_VRS, V(V_DVO), V(V_DVO2), S_VDMA, S_V32, VBASE + VB[buf]
+            rsrc, vl, base, s32, lds0 = S_VRS, V(V_DVO), S_VDMA, S_V32, VBASE + VB[buf]
         out = []
         so = base
-        if piece >= 2:
+        if piece:
             so = S_T[5]
             out.append(I("s_add_u32", so, base, s32))
-        out.append(I("s_add_u32", M0, S_LDSW, lds0 + (0, 1024, 8192, 9216)[piece]))
-        pre, ld = self.buf_op("buffer_load_dwordx4", None, vl2 if piece & 1 else vl, rsrc, so, lds=1, tag=f"dma {which}{piece}")
+        out.append(I("s_add_u32", M0, S_LDSW, lds0 + 4096 * piece))
+        pre, ld = self.buf_op("buffer_load_dwordx4", None, vl, rsrc, so, lds=1, tag=f"dma {which}{piece}")
         return out + pre + [I("s_nop", 0), ld]
 
     def stream_start(self, which):
@@ -532,15 +509,14 @@ class Gen:
 
     def dma_tile(self, which, buf):
         out = []
-        for j in range(4):
+        for j in range(2):
             out += self.dma_piece(which, j, buf)
         out.append(I("s_add_u32", S_KDMA, S_KDMA, S_K64) if which == "k" else I("s_add_u32", S_VDMA, S_VDMA, S_V64))
         return out
 
     def q_stage(self, b: Reg, hh: Reg, qi: Reg):
-        """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the K-tile image (16 pieces of 8 rows x
-        128 bytes: coalesced, ~25 cycles of issue each; the same rows fetched straight into the MFMA operand layout -- 32 rows x
-        32 bytes per instruction -- cost ~210 cycles per load).  Returns (descriptor / offset setup, [pieces])"""
+        """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the K-tile image (8 pieces of 8 rows x
+        128 bytes).  Returns (descriptor / offset setup, [pieces])"""
         setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh, S_QSN)
         setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 5 if self.split else 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
                   I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
@@ -549,65 +525,55 @@ class Gen:
         pieces = []   # (scalar set-up, load): the set-up ends one MFMA gap, the load opens the next (the MFMA between them is the
         # wait state the M0 write needs), like the K / V pieces of phase B
         for R in range(8):
-            for half in range(2):
-                pc = []
-                so = S_T[2]
-                if self.split and R == 4 and not half:
-                    # split row map: the second query block starts 128 rows behind the first (96 = 12 x 8 rows further on)
-                    pc += [I("s_mul_i32", S_X2, S_T[3], 12), I("s_add_u32", S_T[2], S_T[2], S_X2)]
-                if half:
-                    so = S_T[5]
-                    pc.append(I("s_add_u32", so, S_T[2], 128))
-                    if R < 7:
-                        pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
-                pc.append(I("s_add_u32", M0, S_T[4], 2048 * R + 1024 * half))
-                pre, ld = self.buf_op("buffer_load_dwordx4", None, V(V_DQO if R & 1 else V_DQE), S_SQ, so, lds=1, tag=f"qdma R{R} h{half}")
-                pieces.append((pc + pre, ld))
+            pc = []
+            if R:
+                pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
+            if self.split and R == 4:
+                # split row map: the second query block starts 128 rows behind the first (96 = 12 x 8 rows further on)
+                pc += [I("s_mul_i32", S_X2, S_T[3], 12), I("s_add_u32", S_T[2], S_T[2], S_X2)]
+            pc.append(I("s_add_u32", M0, S_T[4], 1024 * R))
+            pre, ld = self.buf_op("buffer_load_dwordx4", None, V(V_DQ[R & 1]), S_SQ, S_T[2], lds=1, tag=f"qdma R{R}")
+            pieces.append((pc + pre, ld))
         return setup, pieces
 
     def q_reads(self):
-        """the staged Q rows -> a[128:191] (fragment (qb, ks) = rows 32 qb + i, 16-byte chunk 2 ks + h, as a K row read)"""
+        """the staged Q rows -> a[64:95] (fragment (qb, ks): rows 32 qb + i, 16-byte chunk 2 ks + h, as a K row read)"""
         out = []
         for qb in range(2):
-            for ks in range(8):
-                out.append(I("ds_read_b128", A_Q(qb, ks), V(V_QRO if ks & 1 else V_QRE), offset=8192 * qb + 512 * (ks >> 1), tag=f"qread qb{qb} ks{ks}"))
+            for ks in range(4):
+                out.append(I("ds_read_b128", A_Q(qb, ks), V(V_QR[ks]), offset=4096 * qb, tag=f"qread qb{qb} ks{ks}"))
         return out
 
     # ------------------------------------------------------------------ the two phases
     def qk_mfmas(self, Y, cinit=None, qbs=(0, 1)):
-        """S^T(next) chains g = 2 qb + kb into score buffer Y.  cinit[g]: None -> C = 0, Reg -> C operand of the first MFMA.
-        qbs: the query blocks whose chains are computed -- the others' MFMAs are None in the returned list (emit_phase)"""
-        out = []
-        if "qk_chain_order" in self.abl:     # (the round's first order: one chain after the other)
-            order = [(g, ks) for g in range(4) for ks in range(8)]
-        else:
-            # the two chains of a query block interleaved: consecutive MFMAs share their B operand (the Q fragment) -- half the
-            # operand toggling of the matrix pipe's inputs, and no MFMA follows the one it accumulates onto
-            order = [(2 * qb + kb, ks) for qb in range(2) for ks in range(8) for kb in range(2)]
-        for g, ks in order:
-            qb, kb = g >> 1, g & 1
-            d = V(Y + 16 * g, 16)
-            c = d if ks else (cinit[g] if cinit and cinit[g] is not None else 0)
-            out.append(I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), c, tag=f"qk g{g} ks{ks}") if qb in qbs else None)
+        """S^T(next) chains g = 2 qb + kb into score buffer Y: 16 MFMAs in a list of 32 SLOTS (a64's phase-A time line): MFMA
+        8 qb + 2 ks + kb stands in slot 2 (8 qb + 2 ks + kb), the other slots are None (emit_phase)"""
+        assert cinit is None
+        out = [None] * 32
+        for qb in range(2):
+            for ks in range(4):
+                for kb in range(2):
+                    d = V(Y + 16 * (2 * qb + kb), 16)
+                    m = I(self.mfma, d, A_K(kb, ks), A_Q(qb, ks), d if ks else 0, tag=f"qk g{2 * qb + kb} ks{ks}")
+                    out[2 * (8 * qb + 2 * ks + kb)] = m if qb in qbs else None
         return out
 
     def v_reads(self, buf):
-        """32 transposed reads of the V tile in VB[buf]: fragment (kstep, db) <- u = 0, 1"""
+        """16 transposed reads of the V tile in VB[buf]: fragment (kstep = 2 kb + s, db), u = 0, 1: keys 32 kb + 16 s + 8 u + 4 h + 0..3"""
         out = []
         for kstep in range(4):
-            for db in range(4):
+            for db in range(2):
                 f = V_F(kstep, db)
                 for u in range(2):
-                    imm = VB[buf] + 2048 * (2 * kstep + u) + 512 * db
-                    out.append(I("ds_read_b64_tr_b16", f.sub(2 * u, 2), V(V_VR1 if u else V_VR0), offset=imm, tag=f"vread ks{kstep} db{db}"))
+                    imm = VB[buf] + 128 * (16 * kstep + 8 * u)
+                    out.append(I("ds_read_b64_tr_b16", f.sub(2 * u, 2), V(V_VR[db]), offset=imm, tag=f"vread ks{kstep} db{db}"))
         return out
 
     def k_reads(self, buf):
         out = []
         for kb in range(2):
-            for ks in range(8):
-                imm = KB[buf] + 8192 * kb + 512 * (ks >> 1)
-                out.append(I("ds_read_b128", A_K(kb, ks), V(V_KRO if ks & 1 else V_KRE), offset=imm, tag=f"kread kb{kb} ks{ks}"))
+            for ks in range(4):
+                out.append(I("ds_read_b128", A_K(kb, ks), V(V_KR[ks]), offset=KB[buf] + 4096 * kb, tag=f"kread kb{kb} ks{ks}"))
         return out
 
     # ------------------------------------------------------------------ the softmax of one tile as a list of placed operations
@@ -643,7 +609,7 @@ class Gen:
         for b in self.b_short_gaps():
             cap_s[32 + b], cap_c[32 + b] = 2.0, 8.0
         # pre-reserved: the V transposed reads of phase A; K reads, DMA pieces and their scalar set-up in phase B
-        for k in range(32):
+        for k in range(16):
             slots[self.a_vread_gap(k)] += 1
             cost[self.a_vread_gap(k)] += 2
         for b, n in self.b_reserved().items():
@@ -667,7 +633,7 @@ class Gen:
         t_mx = {}
         for g in range(4):
             # (chain g's last MFMA is number 8 g + 7, or 16 qb + 14 + kb with the chains of a query block interleaved)
-            t = 8 * g + 11 if "qk_chain_order" in self.abl else 16 * (g >> 1) + 18 + (g & 1)
+            t = 16 * (g >> 1) + 18 + (g & 1)      # (a64's: the chains of query block qb are complete behind slot 16 qb + 12)
             for j in range(8):
                 t = place(t, 5, "mx", (g, j)) + 1
             t_mx[g] = t
@@ -731,9 +697,9 @@ class Gen:
     def b_reserved(self):
         """phase-B gap -> number of pre-reserved fillers (K reads, DMA loads, DMA scalar set-up)"""
         r = {}
-        for k in range(16):
-            r[self.b_kread_gap(k)] = r.get(self.b_kread_gap(k), 0) + 1
         for k in range(8):
+            r[self.b_kread_gap(k)] = r.get(self.b_kread_gap(k), 0) + 1
+        for k in range(4):
             g = self.b_dma_gap(k)
             r[g] = r.get(g, 0) + 1
             r[g - 1] = r.get(g - 1, 0) + 1
@@ -753,7 +719,7 @@ class Gen:
     def b_dma_gap(self, k):
         """phase-B gap whose FIRST filler is DMA piece k's load; its scalar set-up (soffset, M0) ends the gap before, so the MFMA
         between them is the wait state the M0 write needs.  Distinct, two apart, clear of the short row-sum gaps."""
-        return (11, 13, 15, 17, 21, 23, 25, 27)[k]
+        return (11, 15, 21, 25)[k]
 
     def tile_op(self, Sb, kind, payload, init, lazy=None):
         """the instructions of one placed operation, for the tile whose scores live in score buffer Sb.
@@ -1063,27 +1029,29 @@ class Gen:
 
     # ------------------------------------------------------------------ the two phases
     def emit_phase(self, mfmas, gaps):
-        """gaps[k] = fillers behind MFMA k: (order, [insts]) with order 0 = LDS / DMA loads, 1 = exp2, 2 = the rest, 3 = last"""
-        out = []
-        kept = [k for k, m in enumerate(mfmas) if m is not None]
-        if len(kept) == len(mfmas):
-            for k, m in enumerate(mfmas):
-                out.append(m)
-                for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
-                    out += ins
-            return out
-        # some MFMAs are left out (a query block the tile is hidden from): the fillers of the original gaps, each gap's group
-        # kept whole and in the original order, are spread over the remaining MFMAs in proportion -- a filler never moves in
-        # front of an MFMA it followed (check.fix pads what lands too close behind one)
+        """gaps[k] = fillers behind slot k of a64's time line: (order, [insts]) with order 0 = LDS / DMA loads, 1 = exp2, 2 = the rest,
+        3 = last.  Only every fourth slot holds an MFMA here (64 cycles instead of 32): the fillers, in slot order, are cut into one
+        contiguous run per MFMA (the slots it stands for), and a run that is longer than its MFMA's share of the phase's issue cost
+        hands its tail to the next -- the kernel is VALU-issue bound, so what matters is that no MFMA waits behind a longer run than
+        its neighbours'."""
+        from .isa import issue_cost
+        kept = [(k, m) for k, m in enumerate(mfmas) if m is not None]
+        assert kept, "a phase without MFMAs is emitted by its caller"
         n, nk = len(mfmas), len(kept)
-        assert nk > 0, "a phase without MFMAs is emitted by its caller"
-        buckets = [[] for _ in range(nk)]
-        for k in range(n):
-            for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0]):
-                buckets[min(k * nk // n, nk - 1)] += ins
-        for idx, k in enumerate(kept):
-            out.append(mfmas[k])
-            out += buckets[idx]
+        ents = [(min(k * nk // n, nk - 1), ins) for k in range(n) for _, ins in sorted(gaps.get(k, []), key=lambda x: x[0])]
+        cost = [sum(issue_cost(x) for x in ins) for _, ins in ents]
+        length = [32.0 if "32x32x16" in m.op else 16.0 for _, m in kept]
+        total, share = float(sum(cost)), [sum(length[:i + 1]) / sum(length) for i in range(nk)]
+        out, pos, acc = [], 0, 0.0
+        for idx, (_, m) in enumerate(kept):
+            out.append(m)
+            # a filler never moves in FRONT of the MFMA it followed (its origin run `ob`): runs only give work to later ones
+            while pos < len(ents) and ents[pos][0] <= idx and \
+                    (idx == nk - 1 or "slot_buckets" in self.abl or ents[pos][0] < idx or acc + cost[pos] / 2 <= total * share[idx]):
+                out += ents[pos][1]
+                acc += cost[pos]
+                pos += 1
+        assert pos == len(ents)
         return out
 
     def phase_a(self, t4, with_qk=True, cur=True, nxt=True, nxt_init=False, masks=None, steady=False, dma=(), cur_masks=None, extra=(),
@@ -1116,22 +1084,22 @@ class Gen:
         return self.emit_phase(mf, gaps)
 
     def pv_mfmas(self, X, qbs=(0, 1)):
-        """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep) with P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s; behind each
-        k-step the row sums of its two P fragments on the matrix pipe: a 16x16x32 MFMA against the 0 / 1 operand V_ONES puts
-        the 16-key sum of the lane's own query into register 0 of V_LACC[qb] (fa2_mfma16h.hip, FA2_H_MSUM, has the lane maths)"""
-        out = []
+        """O^T[qb][db] += V^T(kstep, db) . P^T(qb, kstep) with P(qb, kstep = 2 kb + s) = X + 16 (2 qb + kb) + 4 s, in a64's 40 phase-B
+        slots: per k-step four products in every second of its eight product slots, then the two row sums (v_mfma_f32_16x16x32
+        against the 0 / 1 operand V_ONES: register 0 of V_LACC[qb] is the lane's own 16-key sum) in the two short slots"""
+        out = [None] * 40
         mfma16 = "v_mfma_f32_16x16x32_" + self.dtype
         for kstep in range(4):
             kb, s = kstep >> 1, kstep & 1
-            for db in range(4):
+            for db in range(2):
                 for qb in range(2):
                     pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                    out.append(I(self.mfma, A_O(qb, db), V_F(kstep, db), pf, A_O(qb, db), tag=f"pv ks{kstep} db{db} qb{qb}")
-                               if qb in qbs else None)
+                    out[10 * kstep + 2 * (2 * db + qb)] = I(self.mfma, A_O(qb, db), V_F(kstep, db), pf, A_O(qb, db),
+                                                            tag=f"pv ks{kstep} db{db} qb{qb}") if qb in qbs else None
             for qb in range(2):
                 pf = V(X + 16 * (2 * qb + kb) + 4 * s, 4)
-                out.append(I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}")
-                           if qb in qbs and "no_rowsum" not in self.abl else None)   # (no_rowsum: timing-only, l stays 0)
+                out[10 * kstep + 8 + qb] = I(mfma16, V(V_LACC[qb], 4), V(V_ONES, 4), pf, V(V_LACC[qb], 4), tag=f"rowsum ks{kstep} qb{qb}") \
+                    if qb in qbs and "no_rowsum" not in self.abl else None
         return out
 
     def phase_b(self, t4, with_pv=True, nxt=True, nxt_init=False, with_kread=True, with_dma=True, steady=False,
@@ -1153,8 +1121,8 @@ class Gen:
             for k, ins in enumerate(self.k_reads((t4 + 2) % self.R)):
                 add(self.b_kread_gap(k), 0, [ins])
         if with_dma:
-            pieces = [self.dma_piece("v", j, (t4 + self.dv) % self.R) for j in range(4)] + \
-                [self.dma_piece("k", j, (t4 + self.dk) % self.R) for j in range(4)]
+            pieces = [self.dma_piece("v", j, (t4 + self.dv) % self.R) for j in range(2)] + \
+                [self.dma_piece("k", j, (t4 + self.dk) % self.R) for j in range(2)]
             for k, pc in enumerate(pieces):
                 if "nodma" in abl:
                     continue
@@ -1203,8 +1171,8 @@ class Gen:
             for qb in range(2):
                 l_skip = self.lab("rescale_skip")
                 blk += [I("s_bitcmp1_b32", S_FLAG, qb), I("s_cbranch_scc0", Label(l_skip)), I("v_mov_b32", co.sub(0), V(V_CO[qb]))]
-                for base in range(0, 64, 8):
-                    regs = [A(qb * 64 + base + k) for k in range(8)]
+                for base in range(0, 32, 8):
+                    regs = [A(qb * 32 + base + k) for k in range(8)]
                     blk += [I("v_accvgpr_read_b32", tmp[k], regs[k]) for k in range(8)]
                     blk += [I("v_pk_mul_f32", V(tmp[k].idx, 2), V(tmp[k].idx, 2), co, op_sel_hi=(1, 0)) for k in range(0, 8, 2)]
                     blk += [I("v_accvgpr_write_b32", regs[k], tmp[k]) for k in range(8)]
@@ -1260,9 +1228,8 @@ class Gen:
 
     def k_epilogue(self):
         """1 / l (one Newton step), L = m + log2 l, O^T -> rows through the wave's LDS slice -> 16-byte row stores, O^T := 0.
-        A workgroup's O tile is 64 KiB and the CU's vector-memory path takes 64 bytes per cycle: the row stores of the first
-        query block are sprinkled through the arithmetic of the second (back to back they cost ~85 cycles each with all four
-        waves storing at once), those of the second run under the MFMAs that zero O and the L arithmetic that is left."""
+        A query block's 32 rows of 128 bytes leave in four stores of eight rows; the stores of the first block are sprinkled through
+        the arithmetic of the second, those of the second run under the MFMAs that zero O."""
         e = self.e
         t = [V(x) for x in V_T]
         e(comment("epilogue: l, 1/l, L; O^T -> rows through the wave's LDS slice -> global; O^T := 0"))
@@ -1282,13 +1249,10 @@ class Gen:
         for qb in range(2):
             e(I("v_fma_f32", inv[qb], l[qb], inv[qb], inv[qb]), I(self.cvt, m2[qb], m2[qb], m2[qb]))
         e(self.stamp_async(0))
-        self.atmp_regs = (V_T[0], V_T[3])     # (the row sums are consumed: V_T[6..9] are LDS addresses from here on)
-        # O: 4 accumulators -> 2 packed registers -> ds_write_b64 at (row i, chunk 4 db + g4, +8 h); one query block at a time.
-        # (S[0] already holds the next job's first scores and v[128:191] its K(1): rows and temporaries are score buffer 1,
-        # whose P was consumed by the job's last P.V.)  A batch = the four 8-byte groups of one 32-column block; the stages
-        # of consecutive batches (accumulator reads | scale | pack, address | LDS write) are woven so that no instruction
-        # waits on its predecessor.
-        rows = [V(SBUF[1] + 4 * k, 4) for k in range(8)]
+        # O: 4 accumulators (four consecutive columns of one query) -> 2 packed registers -> ds_write_b64 at (row i, byte
+        # 64 db + 16 g4 + 8 h); one query block at a time, a batch = one 32-column block.  (S[0] already holds the next job's first
+        # scores and v[128:159] its K(1): rows and temporaries are score buffer 1, whose P was consumed by the job's last P.V.)
+        rows = [V(SBUF[1] + 4 * k, 4) for k in range(4)]
         tset = [[V(SBUF[1] + 32 + 16 * sidx + k) for k in range(16)] for sidx in range(2)]
 
         def weave(*lists):
@@ -1311,60 +1275,55 @@ class Gen:
             return out
 
         def row_stores(qb, off=S_T[0], stride=S_T[1], restride=False):
-            """[[instructions of one row store]] of query block qb (its rows are back in `rows`).  restride: the 4-row stride is
-            formed again in front of every store (scalar code that uses `stride` runs between the stores)"""
+            """[[instructions of one row store]] of query block qb (its rows are back in `rows`): eight rows per store.  restride:
+            the 8-row stride is formed again in front of every store (scalar code that uses `stride` runs between the stores)"""
             pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, off)
-            out = [[I("s_mul_i32", off, S_QROW[qb], S_OSN), I("s_lshl_b32", stride, S_OSN, 2)] + pre + [st]]
-            for k in range(1, 8):
+            out = [[I("s_mul_i32", off, S_QROW[qb], S_OSN), I("s_lshl_b32", stride, S_OSN, 3)] + pre + [st]]
+            for k in range(1, 4):
                 pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, off)
-                out.append(([I("s_lshl_b32", stride, S_OSN, 2)] if restride else []) + [I("s_add_u32", off, off, stride)] + pre + [st])
+                out.append(([I("s_lshl_b32", stride, S_OSN, 3)] if restride else []) + [I("s_add_u32", off, off, stride)] + pre + [st])
             return out
 
         def read_back():
             out = []
-            for k in range(8):   # whole rows: row 4 k + a
-                out.append(I("ds_read_b128", rows[k], V(V_ER), offset=4 * EPI_ROW * k))
+            for k in range(4):   # whole rows: row 8 k + a, 16 bytes per lane as two 8-byte reads (the row stride is 8 mod 16)
+                for u in range(2):
+                    out.append(I("ds_read_b64", rows[k].sub(2 * u, 2), V(V_ER), offset=8 * EPI_ROW * k + 8 * u))
             return out
 
         for qb in range(2):
-            stages = []  # per batch: [reads, muls + address, packs, writes]
-            for db in range(4):
+            stages = []  # per batch: [reads, muls, packs, writes]
+            for db in range(2):
                 tm = tset[db & 1]
                 src = A_O(qb, db)
                 rd = [I("v_accvgpr_read_b32", tm[k], src.sub(k)) for k in range(16)]
-                # (packed fp32 multiplies: half the instructions; beside an MFMA they would cost ~50 cycles each, here the
-                # matrix pipe is idle and every VALU instruction takes the same ~5.8 cycles at one wave per SIMD)
                 mu = [I("v_pk_mul_f32", V(tm[k].idx, 2), V(tm[k].idx, 2), V(inv[qb].idx, 2), op_sel_hi=(1, 0)) for k in range(0, 16, 2)]
                 cv = []
                 for g4 in range(4):
                     cv += [I(self.cvt, tm[4 * g4], tm[4 * g4], tm[4 * g4 + 1]), I(self.cvt, tm[4 * g4 + 1], tm[4 * g4 + 2], tm[4 * g4 + 3])]
-                wr = [I("ds_write_b64", V(V_EW), V(tm[4 * g4].idx, 2), offset=16 * (4 * db + g4)) for g4 in range(4)]
+                wr = [I("ds_write_b64", V(V_EW), V(tm[4 * g4].idx, 2), offset=64 * db + 16 * g4) for g4 in range(4)]
                 stages.append((rd, mu, cv, wr))
-            # software pipeline over the four batches (two register sets): batch b + 1 is read while batch b is scaled, ...
             head = stages[0][0] + weave(stages[0][1], stages[1][0]) + stages[0][2] + stages[0][3]
-            tail = weave(stages[1][1], stages[2][0]) + stages[1][2] + stages[1][3] + weave(stages[2][1], stages[3][0]) + \
-                stages[2][2] + stages[2][3] + stages[3][1] + stages[3][2] + stages[3][3]
+            tail = stages[1][1] + stages[1][2] + stages[1][3]
             e(head)
             if qb == 1:
                 e(self.stamp_async(2))
                 # the first block's rows have been on their way back from LDS since before this block started (four of this
-                # block's writes are younger): wait for them once, then one row store every ~25 instructions
+                # block's writes are younger): wait for them once, then the row stores through the rest of this block
                 e(waitcnt(lgkmcnt=4))
                 e(sprinkle(tail, row_stores(0)))
             else:
                 e(tail)
             e(read_back())
             e(self.stamp_async(1 if qb == 0 else 3))
-        # O^T := 0 and row sums := 0 for the next job; O on the matrix pipe (8 MFMAs instead of 128 v_accvgpr_write)
-        z = V(SBUF[1] + 32, 4)    # (the second block's temporaries: free again)
+        # O^T := 0 and row sums := 0 for the next job; O on the matrix pipe: four MFMAs on zero operands clear 16 accumulators each
+        z = V(V_Z, 4)
         e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
         e([I("v_mov_b32", z.sub(k), 0) for k in range(4)], I("s_nop", 1))
-        # (the wave can issue one of these every 32 cycles and one row store every ~75 with all four waves storing: interleaved,
-        # the stores hide the MFMAs; two MFMAs go first, under the read-back's LDS round trip)
-        zero = [I(self.mfma, A_O(qb, db), z, z, 0) for qb in range(2) for db in range(4)]
+        zero = [I(self.mfma, A_O(qb, db), z, z, 0) for qb in range(2) for db in range(2)]
         # (offset / stride registers the job bookkeeping below leaves alone: k_promote and k_advance use S_T[0..4], [6], [7])
         st1 = row_stores(1, off=S_T[5], stride=S_T[6], restride=True)
-        e(zero[0], zero[1])
+        e(zero[0])
         e(self.stamp_async(4))
         e(waitcnt(lgkmcnt=0))
         e(self.stamp_async_flush((13, 14, 15, 20, 21)))   # (before the scalar code below: it uses the stamp registers)
@@ -1374,21 +1333,19 @@ class Gen:
             pre, st = self.buf_op("buffer_store_short", m2[qb], V(V_L2), S_NVRS, S_T[0])
             e(I("s_lshl_b32", S_T[0], S_QROW[qb], 1), pre, st)
         e(I("s_mov_b64", EXEC, -1))
-        for k in range(8):
+        for k in range(4):
             e(st1[k])
-            if k + 2 < 8:
-                e(zero[k + 2])
-            if k == 1:
-                # Job bookkeeping in the shadow of the row stores (the vector-memory path takes ~75 cycles per store with four
-                # waves storing: the scalar code runs while the first two drain): the next job becomes the current one and the
-                # job after it is decoded -- ~200 cycles that used to stand in front of the seam.  S_FINAL still says "this
-                # job is the workgroup's last" for the branch behind the epilogue: it is put aside in S_FLAG (idle between steps)
+            if k < 3:
+                e(zero[1 + k])
+            if k == 0:
+                # Job bookkeeping in the shadow of the row stores: the next job becomes the current one and the job after it is
+                # decoded.  S_FINAL still says "this job is the workgroup's last" for the branch behind the epilogue: it is put
+                # aside in S_FLAG (idle between steps)
                 l_last = self.lab("epi_last")
                 e(I("s_mov_b32", S_FLAG, S_FINAL), I("s_cmp_lg_u32", S_FINAL, 0), I("s_cbranch_scc1", Label(l_last)))
                 self.k_promote()
-                self.k_advance(vt=(tset[0][4], tset[0][5]))     # (not z: SBUF[1] + 32..35 is the zero MFMAs' operand)
+                self.k_advance(vt=(tset[0][4], tset[0][5]))
                 e(label(l_last))
-        self.atmp_regs = (V_T[8], V_T[9])
 
     # ------------------------------------------------------------------ the whole kernel
     def build(self):
@@ -1411,7 +1368,7 @@ class Gen:
                 e(self.dma_tile("v", j % self.R))
         qs_setup, qs_pieces = self.q_stage(S_B, S_HH, S_QI)
         e(qs_setup, [pc + [I("s_nop", 0), ld] for pc, ld in qs_pieces])
-        e([I("v_accvgpr_write_b32", A(k), 0) for k in range(128)])   # O^T := 0
+        e([I("v_accvgpr_write_b32", A(k), 0) for k in range(64)])   # O^T := 0
         e(waitcnt(vmcnt=0), I("s_barrier"))
         e(self.stamp(1))
         e(self.q_reads(), self.k_reads(0))
@@ -1452,12 +1409,14 @@ class Gen:
                     # four in the quiet end of the next phase A, four in front of the next step's own.  The barrier waits
                     # in between leave them in flight (vmcnt(8 / 12 + ...)); the one of step 2 retires them
                     early += qs_setup
-                    kw.update(own_gaps=(1, 3, 5, 7, 11, 13, 15, 17),
-                              late=[(g, *qs_pieces[k]) for k, g in enumerate((21, 23, 25, 27, 31, 33, 35, 37))])
+                    # (eight pieces here: four behind this step's own K / V pieces, two in the quiet end of the next phase A, two in
+                    # front of the next step's own; the barrier wait of step 1 leaves those six in flight)
+                    kw.update(own_gaps=(1, 5, 11, 15),
+                              late=[(g, *qs_pieces[k]) for k, g in enumerate((21, 25, 29, 33))])
                 if st == 1:
-                    kw.update(vm=self.vm + 12,
-                              dma=[(g, *qs_pieces[8 + k]) for k, g in enumerate((24, 26, 28, 30))],
-                              late=[(g, *qs_pieces[12 + k]) for k, g in enumerate((1, 3, 5, 7))])
+                    kw.update(vm=self.vm + 6,
+                              dma=[(g, *qs_pieces[4 + k]) for k, g in enumerate((24, 28))],
+                              late=[(g, *qs_pieces[6 + k]) for k, g in enumerate((1, 5))])
                 if st == sk:
                     early += kpre
                 if st == sv:
@@ -1581,104 +1540,12 @@ class Gen:
             f"    .wavefront_size: 64"])
 
 
-ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
-             "nodma": ("nodma",), "nokread": ("nokread",), "nostart": ("nostart",), "nofinish": ("nofinish",),
-             "novread": ("novread",), "mfmaonly": ("nodma", "nokread", "nostart", "nofinish", "novread"),
-             "nomx": ("no_mx",), "nodec": ("no_dec",), "nofire": ("no_fire",), "nof": ("no_f",), "noe": ("no_e",), "nocv": ("no_cv",),
-             "nofecv": ("no_f", "no_e", "no_cv"), "nolds": ("nokread", "novread", "nodma"),
-             "nobar_nostart": ("nobarrier", "nostart"), "nobar_nolds": ("nobarrier", "nokread", "novread", "nodma"),
-             "skew": ("skew",), "valuonly": ("nokread", "novread", "nodma", "no_fire"),
-             "fire_nobranch": ("fire_nobranch",)}
-
-
-# named variants of the experiments build (make experiments; FA2_A64_KERNEL=fa2_fwd_a64_bf16_<c|n>_<tag> selects one per launch:
-# benchmarks/variants.py interleaves them in one process, which resolves +-0.3 % -- across gpurun calls boxes differ by 7 %).
-# Measured that way on c3 causal: nolean -1.0 %; plan capacities (6, 26) / (6, 24) / (5, 26) / (5, 25) +-0.3 %, (7, 28) -1.7 %;
-# one-chain-after-the-other QK^T order -0.2 %; zero-operand K and V^T fragments for hidden tiles +0.4 % / 0 (dropped for the
-# lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
-# lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
-# issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)),
-            "norowsum": dict(abl=("no_rowsum",))}     # (norowsum: timing-only bound of what the row-sum MFMAs cost; outputs are wrong)
-
-
-def module_text(gens):
-    head = ['.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', ".amdhsa_code_object_version 6", ".text", ""]
-    body = "\n".join(head) + "\n".join(g.text() for g in gens)
-    md = ["", ".amdgpu_metadata", "---", "amdhsa.kernels:"] + [g.metadata() for g in gens] + [
-        "amdhsa.target: amdgcn-amd-amdhsa--gfx950", "amdhsa.version:", "  - 1", "  - 2", "...", ".end_amdgpu_metadata", ""]
-    return body + "\n".join(md)
-
-
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-o", "--output", required=True)
-    ap.add_argument("--stamps", action="store_true", help="diagnostic build: job-timeline stamps into the debug buffer")
-    ap.add_argument("--variants", action="store_true", help="experiments build: the product kernels plus named variants (A/B in one process)")
-    args = ap.parse_args(argv)
-    from .check import check
-    gens = []
-    for dtype, causal, ragged in [(dt, c, False) for dt in ("bf16", "f16") for c in (False, True)] + \
-            ([] if args.stamps else [(dt, c, True) for dt in ("bf16", "f16") for c in (False, True)]):
-        if True:
-            g = Gen(dtype, causal, stamps=args.stamps, ragged=ragged)
+def product_gens():
+    """the kernels of this generator that ship in libfa2_hip.so's code object (built by fa2_a64_gen.main)"""
+    out = []
+    for dtype in ("bf16", "f16"):
+        for causal in (False, True):
+            g = Gen(dtype, causal)
             g.build()
-            errs = check(g.prog)
-            if errs:
-                print(f"{g.name}: {len(errs)} wait-state violations", file=sys.stderr)
-                return 1
-            gens.append(g)
-    if not args.stamps:   # the same structure on v_mfma_f32_16x16x32 (fa2_a16_gen.py): same code object, same argument block
-        from .fa2_a16_gen import product_gens
-        from .fa2_a8_gen import product_gens as product_gens8
-        from .fa2_a64d_gen import product_gens as product_gens_d64
-        for g in product_gens() + product_gens8() + product_gens_d64():
-            errs = check(g.prog)
-            if errs:
-                print(f"{g.name}: {len(errs)} wait-state violations", file=sys.stderr)
-                return 1
-            gens.append(g)
-    if args.stamps:  # timing-only ablations ride in the diagnostic code object
-        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite", stamps=True, abl=("lite",))
-        g.build()
-        gens.append(g)
-        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_nosplit", stamps=True, abl=("lite",), split=False)
-        g.build()
-        gens.append(g)
-        g = Gen("bf16", True, name="fa2_fwd_a64_bf16_c_lite_noqreads", stamps=True, abl=("lite", "noqreads"))
-        g.build()
-        gens.append(g)
-        for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
-            g = Gen("bf16", False, name=f"fa2_fwd_a64_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
-            g.build()
-            gens.append(g)
-    if args.stamps:     # ... and of the 16x16x32 form (non-causal: its stamp registers are the causal kernels' mask registers)
-        from .fa2_a16_gen import Gen as Gen16
-        for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
-            g = Gen16("bf16", False, name=f"fa2_fwd_a16_bf16_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
-            g.build()
-            gens.append(g)
-        g = Gen16("bf16", True, name="fa2_fwd_a16_bf16_c_lite", stamps=True, abl=("lite",))
-        g.build()
-        gens.append(g)
-        from .fa2_a8_gen import Gen as Gen8      # ... and of the fp8 form
-        g = Gen8("e4m3", False, stamps=True)     # (the plain name: the launcher looks it up before FA2_A64_KERNEL replaces it)
-        g.build()
-        gens.append(g)
-        for nm, abl in [("lite", ())] + list(ABLATIONS.items()):
-            g = Gen8("e4m3", False, name=f"fa2_fwd_a8_e4m3_n_{nm}", stamps=True, abl=tuple(abl) + ("lite",))
-            g.build()
-            gens.append(g)
-    if args.variants:   # selected at run time through FA2_A64_KERNEL in the experiments library (benchmarks/variants.py)
-        for tag, kw in VARIANTS.items():
-            for causal in (False, True):
-                g = Gen("bf16", causal, name=f"fa2_fwd_a64_bf16_{'c' if causal else 'n'}_{tag}", **kw)
-                g.build()
-                gens.append(g)
-    with open(args.output, "w") as f:
-        f.write(module_text(gens))
-    return 0
-
-
-if __name__ == "__main__":
-    sys.exit(main())
+            out.append(g)
+    return out

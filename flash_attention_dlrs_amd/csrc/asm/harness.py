@@ -57,7 +57,7 @@ def pack_kargs(ptrs, strides_bh, strides_n, N, H, nq, total, c, thr, nunit, G, n
 def run(prog, Q, K, V, dtype="bf16", causal=False, scale=1.0, nwg=None, order=None, G=1, pow2=True, thr_override=None, pairs=False):
     """Q, K, V: float32 arrays (B, H, N, 128), rounded to dtype here.  Returns O (B,H,N,128) f32, L (B,H,N) f32."""
     B, H, N, D = Q.shape
-    assert D == 128
+    assert D in (64, 128)      # (128: a64, a16, a8;  64: a64d)
     mem = Memory()
     bufs = {}
     for nm, x in (("Q", Q), ("K", K), ("V", V)):

@@ -41,6 +41,7 @@ struct DevState {
     hipModule_t mod = nullptr;
     hipFunction_t fn[2][2][2][2] = {};  // [a64 / a16][bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
     hipFunction_t fn8[2] = {};          // a8: [e4m3 / e5m2], non-causal, N % 256 == 0
+    hipFunction_t fnd[2][2] = {};       // a64d (head size 64): [bf16 / f16][non-causal / causal], N % 256 == 0
     int cus = 0;
 };
 DevState g_dev[kMaxDev];
@@ -84,6 +85,13 @@ DevState *dev_state() {
         e = hipModuleGetFunction(&d.fn8[t], d.mod, t ? "fa2_fwd_a8_e5m2_n" : "fa2_fwd_a8_e4m3_n");
         if (e != hipSuccess) d.fn8[t] = nullptr;
     }
+    for (int t = 0; t < 2; ++t)
+        for (int c = 0; c < 2; ++c) {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "fa2_fwd_a64d_%s_%s", t ? "f16" : "bf16", c ? "c" : "n");
+            e = hipModuleGetFunction(&d.fnd[t][c], d.mod, nm);
+            if (e != hipSuccess) d.fnd[t][c] = nullptr;
+        }
     (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
     d.cus = fa2_device_cus();
     d.ready = true;
@@ -134,6 +142,26 @@ bool fa2_a8_supports(const Fa2Problem &p) {
 }
 int fa2_launch_a8(const Fa2Problem &p) { return launch(p, 2); }
 
+// head size 64, f16 / bf16: rows of 128 bytes; N a multiple of 256 (no ragged form); otherwise the conditions of a64
+bool fa2_a64d_supports(const Fa2Problem &p) {
+    if (p.dtype != FA2_DTYPE_BF16 && p.dtype != FA2_DTYPE_F16) return false;
+    if (p.d != 64 || p.N < 256 || (p.N & 255)) return false;
+    if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
+    if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
+    const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
+    for (int k = 0; k < 4; ++k)
+        if (rows[k] < 64 || (rows[k] & 7) || (int64_t)(p.N + 512) * rows[k] * 2 >= (1LL << 31)) return false;
+    const uintptr_t ptrs[4] = {(uintptr_t)p.Q, (uintptr_t)p.K, (uintptr_t)p.V, (uintptr_t)p.O};
+    for (int k = 0; k < 4; ++k)
+        if (ptrs[k] & 15) return false;
+    if (((p.qs[0] | p.qs[1] | p.ks[0] | p.ks[1] | p.vs[0] | p.vs[1] | p.os[0] | p.os[1]) & 7) != 0) return false;
+    if ((uintptr_t)p.L & 1) return false;
+    const int64_t nq = p.N / 256, jobs = (int64_t)p.B * p.H * nq;
+    if (jobs >= (1 << 22) || p.H >= (1 << 22) || p.ls[1] < p.N) return false;
+    return true;
+}
+int fa2_launch_a64d(const Fa2Problem &p) { return launch(p, 3); }
+
 
 
 // The a16 kernels take what the a64 kernels take (same argument block, same job stream).
@@ -143,8 +171,13 @@ int fa2_launch_a16(const Fa2Problem &p) { return launch(p, 1); }
 
 namespace {
 int launch(const Fa2Problem &p, int shape16) {
-    const bool f8 = shape16 == 2;
-    if (f8) {
+    const bool f8 = shape16 == 2, d64 = shape16 == 3;
+    if (d64) {
+        if (!fa2_a64d_supports(p)) {
+            fa2_set_error("a64d kernel: needs f16/bf16, d = 64, N a multiple of 256, unit d-stride, 16-byte aligned rows, scale > 0");
+            return FA2_ERR_UNSUPPORTED;
+        }
+    } else if (f8) {
         if (!fa2_a8_supports(p)) {
             fa2_set_error("a8 kernel: needs fp8 (e4m3fn / e5m2), d = 128, N a multiple of 256, no mask, unit d-stride, 16-byte aligned rows");
             return FA2_ERR_UNSUPPORTED;
@@ -157,9 +190,10 @@ int launch(const Fa2Problem &p, int shape16) {
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
     hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0]
-                          : d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
+                     : d64 ? d->fnd[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0]
+                           : d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {
-        fa2_set_error("%s kernel: this (dtype, causal, ragged N) form is not in the code object", f8 ? "a8" : shape16 ? "a16" : "a64");
+        fa2_set_error("%s kernel: this (dtype, causal, ragged N) form is not in the code object", f8 ? "a8" : d64 ? "a64d" : shape16 ? "a16" : "a64");
         return FA2_ERR_UNSUPPORTED;
     }
     A64Args a;
@@ -194,7 +228,7 @@ int launch(const Fa2Problem &p, int shape16) {
     // instead of each starting again at tile 0 at a time of its own.  The order is a function of (query block, nq) alone, so a
     // head's result does not depend on the launch it is part of (bit-identical head sharding).  Same-device A/B against
     // FA2_A64_PAIRS=0 (profiles/r03/pairs_ab.jsonl): c3 +1 %, N = 2048 +2.8 %, N >= 8192 0 .. -0.6 % (left alone there).
-    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && shape16 == 0;
+    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && (shape16 == 0 || d64);
 #ifdef FA2_A64_STAMPS
     down = false;      // (the diagnostic kernels use the registers for the debug pointer)
 #endif

@@ -76,6 +76,11 @@ int pick_variant(const Fa2Problem &p) {
         // MFMA16D_W4 / MFMA16H / MFMA16K it is 4-33 % faster on every shape from those sizes up (the persistent grid also
         // takes job counts that are not a multiple of the CU count better: 1.5 jobs per CU 180 vs 213 us); on the same
         // MI355X against MFMA16H: c3 causal +15-19 %, c3 shape non-causal +15-17 %.
+        // head size 64, N a multiple of 256: the generated kernel at d = 64 (A64D, asm/fa2_a64d_gen.py) under a64's grid rule.
+        // Same-device A/B against the rest of this table (profiles/r03/a64d_vs_table.jsonl), bf16 / f16: B8 H16 N4096 1 013 vs 840
+        // TFLOP/s (+21 %), causal 1 014 vs 827 (+23 %); N = 8192 1 092 vs 929, causal 1 060 vs 887; B16 H32 N2048 984 vs 821,
+        // causal 860 vs 677 (+27 %)
+        if (fa2_a64d_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) return FA2_VARIANT_A64D;
         if (fa2_a64_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) {
             // The same kernel on the other matrix shape (A16: v_mfma_f32_16x16x32, asm/fa2_a16_gen.py): 15 % more cycles per key
             // step, but the chip holds a 10-17 % higher clock under it.  Same-device A/B against A64 (benchmarks/variants.py,
@@ -122,11 +127,12 @@ int pick_variant(const Fa2Problem &p) {
         // shape (N = 4096), +4 % (N = 2048), +2.6 % (N = 8192), +2.5 % (N = 16384), +2.4 % (d = 64).
         return FA2_VARIANT_MFMA16H;
     }
-    // fp8, no mask, N a multiple of 256: the generated kernel A8 (asm/fa2_a8_gen.py: the A64 structure -- 4 waves x 64 rows, one wave
-    // per SIMD -- on v_mfma_f32_32x32x64_f8f6f4), bit-identical to MFMA8X.  Same-device A/B (benchmarks/variants.py,
-    // profiles/r03/a8_vs_mfma8x.jsonl): BASELINE configs[4]'s per-GPU shard (B16 H8 N16384) 2 266 vs 2 164 TFLOP/s (+4.7 %), B4 H32
-    // N4096 +1.4 .. 2.7 %, N = 1024 +-1 %: from N = 2048 on and at least a quarter of the CUs busy.
-    if (fa2_a8_supports(p) && p.N >= 2048 && (long long)(p.N / 256) * p.B * p.H >= T(64)) return FA2_VARIANT_A8;
+    // (The generated fp8 kernel A8 -- asm/fa2_a8_gen.py: the A64 structure on v_mfma_f32_32x32x64_f8f6f4, bit-identical to MFMA8X --
+    // is NOT the default: which of the two is faster depends on the data.  BASELINE configs[4]'s per-GPU shard (B16 H8 N16384), same
+    // device: inputs N(0, 0.25), scores of sigma 4 log2 units: A8 2 266 .. 2 309 vs 2 164 .. 2 191 TFLOP/s (+5 %); inputs N(0, 1) as
+    // SURVEY section 8d draws them, sigma 16: the running maximum passes the 6-unit deferral threshold of fp8 P in a quarter of the
+    // tile steps, and a rescale of O costs the one wave of a SIMD ~900 cycles with nothing else to run there: A8 2 080 vs 2 216.
+    // profiles/r03/a8_vs_mfma8x.jsonl.  FA2_AUTOTUNE=1 times both on the caller's tensors.)
     if (fa2_mfma8x_supports(p)) {
         // fp8: the double-rate k = 64 MFMA (64-key units).  Against MFMA8 (32x32x16 fp8, the bf16 rate) on MI355X:
         // +26 % at the c5 per-GPU shape (N = 16384 non-causal: 1 880 vs 1 492 TFLOP/s), +19 % at c3 causal.
@@ -179,6 +185,7 @@ int run(const Fa2Problem &p, int variant) {
     case FA2_VARIANT_A64: return fa2_launch_a64(p);
     case FA2_VARIANT_A16: return fa2_launch_a16(p);
     case FA2_VARIANT_A8: return fa2_launch_a8(p);
+    case FA2_VARIANT_A64D: return fa2_launch_a64d(p);
 #ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA16S: return fa2_launch_mfma16s(p, 8);
     case FA2_VARIANT_MFMA16S_W4: return fa2_launch_mfma16s(p, 4);
@@ -322,6 +329,7 @@ int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_
     case FA2_VARIANT_A64: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_A16: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
     case FA2_VARIANT_A8: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
+    case FA2_VARIANT_A64D: out4[1] = 256; out4[2] = 64; out4[3] = 4; break;
 #ifdef FA2_EXPERIMENTS
     case FA2_VARIANT_MFMA8: out4[1] = 256; out4[2] = 32; out4[3] = 8; break;
     case FA2_VARIANT_MFMA8_W4: out4[1] = 128; out4[2] = 32; out4[3] = 4; break;

@@ -40,6 +40,8 @@ int fa2_launch_a16(const Fa2Problem &p);  // the same structure on v_mfma_f32_16
 bool fa2_a16_supports(const Fa2Problem &p);
 int fa2_launch_a8(const Fa2Problem &p);   // ... and on the fp8 matrix path, v_mfma_f32_32x32x64_f8f6f4 (asm/fa2_a8_gen.py)
 bool fa2_a8_supports(const Fa2Problem &p);
+int fa2_launch_a64d(const Fa2Problem &p); // ... and at head size 64 (asm/fa2_a64d_gen.py)
+bool fa2_a64d_supports(const Fa2Problem &p);
 bool fa2_mfma8_supports(const Fa2Problem &p);
 bool fa2_mfma8x_supports(const Fa2Problem &p);
 bool fa2_mfma16_supports(const Fa2Problem &p);
