@@ -80,7 +80,10 @@ int pick_variant(const Fa2Problem &p) {
         // Same-device A/B against the rest of this table (profiles/r03/a64d_vs_table.jsonl), bf16 / f16: B8 H16 N4096 1 013 vs 840
         // TFLOP/s (+21 %), causal 1 014 vs 827 (+23 %); N = 8192 1 092 vs 929, causal 1 060 vs 887; B16 H32 N2048 984 vs 821,
         // causal 860 vs 677 (+27 %)
-        if (fa2_a64d_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) return FA2_VARIANT_A64D;
+        // Grid rule from the d = 64 mid-grid sweep (benchmarks/mid_grid.py, profiles/r03/mid_grid_d64.jsonl, 48 shapes): from 192 jobs
+        // of 256 rows on A64D is the best of the six kernels or within 4 % of it; below, the key-split and 128-row kernels keep more
+        // CUs busy (64 jobs: 13.1 us for MFMA16K_R2K4 against 17.0)
+        if (fa2_a64d_supports(p) && wg256 >= T(p.causal ? 192 : 160)) return FA2_VARIANT_A64D;
         if (fa2_a64_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) {
             // The same kernel on the other matrix shape (A16: v_mfma_f32_16x16x32, asm/fa2_a16_gen.py): 15 % more cycles per key
             // step, but the chip holds a 10-17 % higher clock under it.  Same-device A/B against A64 (benchmarks/variants.py,

@@ -307,6 +307,42 @@ def test_two_streams_at_once():
     assert torch.equal(Oa, Oa2) and torch.equal(La, La2) and torch.equal(Ob, Ob2) and torch.equal(Lb, Lb2)
 
 
+# ----------------------------------------------------------------------------- head size 64: the generated kernel a64d
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_a64d_head_size_64(oracle, dtype, causal):
+    """the generated kernel at d = 64 (asm/fa2_a64d_gen.py): seeded inputs against the oracle, many jobs per workgroup against SDPA,
+    (B, N, H, d)-strided inputs, element-wise against the oracle's deferred-maximum mode (>= 99 % of O bit-identical), and
+    bit-identical head shards (causal: light jobs walk downwards as a function of the query block alone)"""
+    for shape in ((1, 1, 256), (2, 3, 512), (1, 2, 768), (1, 5, 1024)):
+        B, H, N = shape
+        Q, K, V = rand3((B, H, N, 64), dtype, seed=N + H)
+        f = lambda t: t.float().contiguous().numpy()
+        O_ref, L_ref = oracle.forward(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, B_r=64, B_c=64)
+        check(*a64(Q, K, V, causal, variant="a64d"), torch.from_numpy(O_ref), torch.from_numpy(L_ref), dtype)
+    Q, K, V = rand3((3, 48, 1536, 64), dtype, seed=9)        # 864 jobs on 256 workgroups, B * H not a power of two
+    O, L = a64(Q, K, V, causal, variant="a64d")
+    ref = torch.nn.functional.scaled_dot_product_attention(Q.to(DEV).float(), K.to(DEV).float(), V.to(DEV).float(), scale=1.0, is_causal=causal).cpu()
+    assert torch.isfinite(O.float()).all() and (O.float() - ref).abs().max() <= O_TOL[dtype]
+    parts = [a64(Q[:, h0:h0 + 12].contiguous(), K[:, h0:h0 + 12].contiguous(), V[:, h0:h0 + 12].contiguous(), causal, variant="a64d")[0]
+             for h0 in range(0, 48, 12)]
+    assert torch.equal(torch.cat(parts, dim=1), O)
+    gen = torch.Generator().manual_seed(21)
+    Qs, Ks, Vs = (torch.randn(2, 512, 3, 64, generator=gen).to(dtype).transpose(1, 2) for _ in range(3))
+    Os, _ = a64(Qs, Ks, Vs, causal, variant="a64d")
+    Oc, _ = a64(Qs.contiguous(), Ks.contiguous(), Vs.contiguous(), causal, variant="a64d")
+    assert torch.equal(Os, Oc)
+    Q, K, V = rand3((1, 2, 512, 64), dtype, seed=77)
+    K[:, :, 300] = (Q[:, :, 200].float() * 0.9).to(dtype)
+    O, L = a64(Q, K, V, causal, variant="a64d")
+    f = lambda t: t.float().numpy()
+    O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
+                                           thr=60.0 if dtype == torch.bfloat16 else 15.875, sum_rounded=True)
+    assert (O.float() == torch.from_numpy(O_ref)).float().mean().item() >= 0.99
+    assert _lib.query_tile(4096, 64, _lib.FA2_DTYPE_BF16, causal, B=8, H=16)[0] == _lib.VARIANT_A64D
+    assert _lib.query_tile(4000, 64, _lib.FA2_DTYPE_BF16, causal, B=8, H=16)[0] != _lib.VARIANT_A64D      # no ragged form
+
+
 def test_first_launch_of_the_process_under_stream_capture():
     """"safe under stream capture" -- for the default kernel too, whose first launch on a device loads its code
     object (hipModuleLoadData): a fresh process captures variant "a64" into a HIP graph with NO warm-up call, replays it on new

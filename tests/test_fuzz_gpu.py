@@ -53,6 +53,8 @@ def test_random_shape(B, H, N, d, dtype, causal):
         fwd_variants += ["a64"]      # (its plain form when N is a multiple of 256, the ragged one otherwise)
         if N % 256 == 0:
             fwd_variants += ["a16"]  # (the 16x16x32 form has no ragged kernels)
+    if dtype != torch.float32 and d == 64 and N >= 256 and N % 256 == 0:
+        fwd_variants += ["a64d"]     # (the generated kernel at head size 64)
     if dtype == torch.float32 and d in (64, 128):
         fwd_variants += ["mfma32"]
     for v in fwd_variants:
