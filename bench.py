@@ -171,7 +171,9 @@ def profiled_traffic(config, variant):
     scripts/gpu_prof.sh).  bench.py cannot collect PMC counters itself; None if no summary is committed."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{config}_*_rocprof.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{config}_*_rocprof.json")))
+    files = [f for f in files if f"_{variant}_" in os.path.basename(f)] or files     # (the pass of the kernel that runs, if there is one)
+    for f in files:
         try:
             with open(f) as fh:
                 d = json.load(fh)

@@ -119,6 +119,22 @@ class PW:
                 e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
                 for x in sorted(groups[2 * u] + groups[2 * u + 1], key=lambda i: 0 if i.op.startswith("ds_") else 1 if i.op == "v_exp_f32" else 2):
                     e(x)
+        elif shape == "mix":
+            # half the FLOPs on each shape (QK^T on 32x32x16, P.V on 16x16x32 -- the hybrid kernel), plus the two lane-group
+            # exchanges that turn packed P of the 32x32 layout into 16x16x32 operands
+            SWP = lambda k: I("v_permlane16_swap_b32", V(r(k)), V(r(k + 7)))
+            for u in range(4):
+                acc = A(16 * u, 16)
+                e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
+                for x in sorted(groups[2 * u] + groups[2 * u + 1], key=lambda i: 0 if i.op.startswith("ds_") else 1 if i.op == "v_exp_f32" else 2):
+                    e(x)
+            for v in range(8, 16):
+                acc = A(64 + 4 * v, 4)
+                e(I("v_mfma_f32_16x16x32_bf16", acc, V(128 + 4 * (v // 4), 4), V(160 + 4 * (v % 8), 4), acc))
+                for x in sorted(groups[v], key=lambda i: 0 if i.op.startswith("ds_") else 1 if i.op == "v_exp_f32" else 2):
+                    e(x)
+                if fill is not None and v in (9, 13):
+                    e(SWP(11 * v))
         else:
             for v in range(16):
                 acc = A(4 * v, 4)
@@ -160,7 +176,7 @@ class PW:
 
 def cases():
     out = []
-    for shape in ("32", "16"):
+    for shape in ("32", "16", "mix"):
         out.append(PW(f"pw_{shape}_bare", shape, None))
         out.append(PW(f"pw_{shape}_full", shape, "full"))
         out.append(PW(f"pw_{shape}_noexp", shape, "noexp"))
