@@ -451,7 +451,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(c)
 
-    traffic = profiled_traffic(args.config, variant) if args.variant == "auto" else None
+    picked = {v: k for k, v in _lib.VARIANTS.items()}.get(tile[0], variant)      # the name of the kernel the table picked
+    traffic = profiled_traffic(args.config, picked) if args.variant == "auto" else None
     if rank == 0:
         out = {
             "metric": f"attention fwd TFLOP/s per GPU (B={c['B']},H={c['H']},N={c['N']},d={c['d']} {c['dtype']}); % MFMA peak",

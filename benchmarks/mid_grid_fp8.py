@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""fp8 (e4m3) counterpart of mid_grid.py: mfma8x (8 waves) vs mfma8x_w4 vs mfma8u over grids of 64..2048 256-row tiles."""
+"""fp8 (e4m3) counterpart of mid_grid.py: mfma8x (8 waves) vs mfma8x_w4 vs mfma8u -- and, non-causal with N a multiple of 256, the
+generated a8 -- over grids of 64..2048 256-row tiles.  MID_GRID_SPREAD: standard deviation of the inputs (default 1: bench.py's)."""
 import json
 import os
 import sys
@@ -27,15 +28,16 @@ def t(fn, it=20):
     return best
 
 
-for causal in (False, True):
-    for N in (1024, 2048, 4096, 8192):
+for causal in ((False,) if os.environ.get("MID_GRID_NONCAUSAL") else (False, True)):
+    for N in (512, 1024, 2048, 4096, 8192):
         for BH in (8, 16, 24, 32, 48, 64, 128):
             wg256 = BH * ((N + 255) // 256)
             if wg256 < 64 or wg256 > 2100:
                 continue
-            Q, K, V = ((torch.randn(1, BH, N, 128, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in range(3))
+            Q, K, V = ((torch.randn(1, BH, N, 128, device=dev) * float(os.environ.get("MID_GRID_SPREAD", "1.0"))).to(torch.float8_e4m3fn) for _ in range(3))
             r = {"causal": causal, "N": N, "BH": BH, "wg256": wg256}
-            for v in ("auto", "mfma8x", "mfma8x_w4", "mfma8u"):
+            cands = ("mfma8x", "mfma8x_w4") + (() if causal or N % 256 else ("a8",))     # (mfma8u: experiments library only)
+            for v in ("auto",) + cands:
                 r[v] = round(t(lambda: flash_attention_forward(Q, K, V, dev, causal=causal, variant=v)), 1)
-            r["best"] = min(("mfma8x", "mfma8x_w4", "mfma8u"), key=lambda k: r[k])
+            r["best"] = min(cands, key=lambda k: r[k])
             print(json.dumps(r), flush=True)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--pairs", default="c3:mfma16_w8,c3:mfma16,c3_noncausal:mfma16_w8,c3_noncausal:mfma16")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--fp8-spread", type=float, default=0.5, help="standard deviation of the fp8 inputs (bench.py draws N(0, 1))")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     # pair = config:variant[:ENV=VALUE[+ENV=VALUE...]] -- the env settings are applied around that pair's launches
@@ -42,7 +43,7 @@ def main():
             c = CONFIGS[cfg]
             torch.manual_seed(42)
             data[cfg] = tuple((torch.randn(c["B"], c["H"], c["N"], c["d"], device=dev) *
-                               (0.5 if c["dtype"] == "fp8" else 1.0)).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
+                               (args.fp8_spread if c["dtype"] == "fp8" else 1.0)).to(TORCH_DTYPE[c["dtype"]]) for _ in range(3))
     res = {f"{c}:{v}": [] for c, v in pairs}
     for cfg, var in pairs:  # warm-up
         Q, K, V = data[cfg]

@@ -1675,6 +1675,8 @@ def main(argv=None):
                 g = Gen("bf16", causal, name=f"fa2_fwd_a64_bf16_{'c' if causal else 'n'}_{tag}", **kw)
                 g.build()
                 gens.append(g)
+        from .fa2_a8_gen import variant_gens as variant_gens8
+        gens += variant_gens8()
     with open(args.output, "w") as f:
         f.write(module_text(gens))
     return 0

@@ -2,7 +2,10 @@
 """Generator of the gfx950 assembly kernels `fa2_fwd_a8_<e4m3|e5m2>_n` -- FA-2 forward, d = 128, OCP fp8 (BASELINE.json
 configs[4]): the a64 structure (fa2_a64_gen.py: 4 waves x 64 query rows, one wave per SIMD with all 512 registers, persistent
 grid, continuous tile stream, LDS-DMA staging, modulo-scheduled softmax) on the double-rate fp8 matrix path,
-v_mfma_f32_32x32x64_f8f6f4 (both operands plain fp8: no block scales).
+v_mfma_f32_32x32x64_f8f6f4 -- QK^T on the plain form, P.V on the BLOCK-SCALED one (Gen.scaled): the running maximum is an integer,
+the O accumulators stay relative to the job's first maximum and P's E8M0 scale operand carries the power of two between them, so O is
+never rescaled (a rescale costs the one wave of a SIMD ~900 cycles with the other three at the barrier; fp8 P leaves only 8.5 log2
+units of deferral).
 
 Reference arithmetic: /root/reference/src/flash_attention_kernels.py:84-108 with the reference's fp8 dtype path
 (src/flash_attention_torch.py:14-15): fp32 S, m, l, O; P rounded RTNE to fp8 before P.V; O / l and L rounded to fp8 on store --
@@ -48,6 +51,14 @@ V_LACC = (216, 220)       # row-sum accumulators of the two query blocks (4 regi
 V_ST_LAST, V_ST_ACC = 224, 225   # diagnostic builds: last stamp (low word), accumulators [3]
 V_NINF = 231
 NINF = V(V_NINF)
+# block-scaled P.V (Gen.scaled): the running maximum moves in INTEGER steps and O is never rescaled -- the power of two goes into the
+# MFMA's per-lane scale operand of P instead
+V_B = (232, 233)          # 127 - m_O per query block (m_O: the integer reference of the O accumulators): scale byte = m + V_B
+V_SCL = (234, 235)        # the E8M0 scale byte (byte 0) of the P operands whose P.V runs: 127 + (m - m_O)
+V_SCP = (236, 237)        # ... the one that takes over at the end of this phase B (a decision of the tile that starts)
+V_CO2 = (238, 239)        # guard path (m - m_O would pass KMAX): the factor 2^-(m - m_O) that re-bases O
+V_S127 = 240              # the scale byte of the V^T operand: 127 = 2^0
+KMAX = 64                 # largest m - m_O before O is re-based: 2^(64 + 8.5) N max|V| stays far inside fp32, 2^-64 / l above its denormals
 
 
 # AGPRs
@@ -129,12 +140,19 @@ NSLOT = 24
 
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
-                 caps=(5, 24), split=True):
+                 caps=(5, 24), split=True, scaled=True):
         assert dtype in ("e4m3", "e5m2") and not causal and not ragged, "a8: OCP fp8, non-causal, N a multiple of 256"
         self.dtype = dtype
+        # scaled: P.V on v_mfma_scale_f32_32x32x64_f8f6f4.  fp8 P leaves 8.5 log2 units of deferral (e4m3 tops out at 448): on N(0, 1)
+        # inputs at scale 1 (scores of sigma 16) a row's maximum passes it in a quarter of the tile steps, and a rescale of 64
+        # accumulators costs the one wave of a SIMD ~900 cycles with the other three waiting at the barrier.  Here the running maximum
+        # is an INTEGER (the ceiling of the row maximum in the exp2 domain), O stays relative to the job's first maximum m_O, and
+        # the P operand carries 2^(m - m_O) as its E8M0 block scale: raising m costs a dozen VALU operations and no accumulator
+        # access (the row sums, four registers, are scaled by an exact power of two).  The guard re-bases O when m - m_O passes KMAX.
+        self.scaled = scaled
         self.fmt = dict(cbsz=1, blgp=1) if dtype == "e5m2" else {}     # operand formats of the f8f6f4 MFMAs (0 = e4m3, 1 = e5m2)
         self.causal = causal
-        self.name = name or f"fa2_fwd_a8_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
+        self.name = name or f"fa2_fwd_a8_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}{'' if scaled else '_unscaled'}"
         self.atmp = 0          # (ragged) which of the two address temporaries the next buffer operation takes
         self.atmp_regs = (V_T[8], V_T[9])
         self.prog: list[Inst] = []
@@ -380,6 +398,9 @@ class Gen:
         e([I("v_cndmask_b32", V(V_ONES + k), 0, t2, VCC) for k in range(8)])
         e([I("v_mov_b32", V(V_LACC[qb] + k), 0) for qb in range(2) for k in range(4)])
         e([I("v_mov_b32", V(V_CO[qb]), 1.0) for qb in range(2)])
+        if self.scaled:
+            e([I("v_mov_b32", V(r), 127) for r in V_SCL + V_SCP + (V_S127,)], [I("v_mov_b32", V(r), 0) for r in V_B],
+              [I("v_mov_b32", V(r), 1.0) for r in V_CO2])
         # ---- scalar constants
         e(I("s_lshl_b32", S_K32, S_KSN, 5), I("s_lshl_b32", S_V32, S_VSN, 5),
           I("s_lshl_b32", S_K64, S_KSN, 6), I("s_lshl_b32", S_V64, S_VSN, 6),
@@ -737,6 +758,9 @@ class Gen:
             if part == 1:
                 return [I("v_permlane32_swap_b32", a, b)] if full else []
             if part == 2:
+                if init and self.scaled:    # (an integer reference: every later m is m_O plus an integer, every factor an exact power of two)
+                    return [I("v_max_f32", a, a, b), I("v_mul_f32", V(V_MC[qb]), S_C, a), I("v_ceil_f32", V(V_MC[qb]), V(V_MC[qb])),
+                            I("v_sub_f32", V(V_B[qb]), 127.0, V(V_MC[qb]))]
                 if init:
                     return [I("v_max_f32", a, a, b), I("v_mul_f32", V(V_MC[qb]), S_C, a)]
                 return ([I("v_max_f32", a, a, b)] if full else []) + [I("v_fma_f32", d, a, S_C, -V(V_MC[qb]))]
@@ -752,6 +776,21 @@ class Gen:
             t2, t3 = V(V_T[2 + 2 * qb]), V(V_T[3 + 2 * qb])
             exact = self.fire_exact(Sb, qb, lazy) if lazy is not None else []
             swap = [] if "full_max" in self.abl else [I("v_mov_b32", b, a), I("v_permlane32_swap_b32", a, b), I("v_max_f32", a, a, b)]
+            if self.scaled:
+                # m := max(m, ceil(c * max)) -- an integer step; the row sums (relative to m) take the exact factor 2^(m_old - m) at
+                # the end of this phase B, where the new scale byte 127 + (m - m_O) becomes the P operands' (this phase's P.V still
+                # runs on the tile that was rounded against the old m).  Guard: m - m_O > KMAX -> O is re-based to m as well
+                l_guard, l_gback = self.lab("guard"), self.lab("guard_back")
+                self.ool.append([label(l_fire)] + exact + swap +
+                                [I("v_mul_f32", t2, S_C, a), I("v_ceil_f32", t2, t2), I("v_max_f32", t2, t2, V(V_MC[qb])),
+                                 I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
+                                 I("v_add_f32", t3, t2, V(V_B[qb])), I("v_cvt_u32_f32", V(V_SCP[qb]), t3),
+                                 I("v_cmp_lt_f32", VCC, 127.0 + KMAX, t3), I("s_or_b32", S_FLAG, S_FLAG, 1 << qb),
+                                 I("s_cbranch_vccnz", Label(l_guard)), label(l_gback), I("s_branch", Label(l_back)),
+                                 label(l_guard), I("v_sub_f32", t3, 127.0, t3), I("v_exp_f32", V(V_CO2[qb]), t3),
+                                 I("v_sub_f32", V(V_B[qb]), 127.0, t2), I("v_mov_b32", V(V_SCP[qb]), 127),
+                                 I("s_or_b32", S_FLAG, S_FLAG, 4 << qb), I("s_branch", Label(l_gback))])
+                return [I("s_cmp_lg_u64", S_FIRE[qb], 0), I("s_cbranch_scc1", Label(l_fire)), label(l_back)]
             self.ool.append([label(l_fire)] + exact + swap + [I("v_mul_f32", t2, S_C, a), I("v_max_f32", t2, t2, V(V_MC[qb])),
                              I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
                              I("s_or_b32", S_FLAG, S_FLAG, 1 << qb), I("s_branch", Label(l_back))])
@@ -1083,6 +1122,10 @@ class Gen:
         seq = []
         for db in range(4):
             for qb in range(2):
+                if self.scaled:
+                    seq.append(I("v_mfma_scale_f32_32x32x64_f8f6f4", A_O(qb, db), V_F(db), P_OP(X, qb), A_O(qb, db), V(V_S127), V(V_SCL[qb]),
+                                 op_sel_hi=(0, 0, 0), tag=f"pv db{db} qb{qb}", **self.fmt) if qb in qbs else None)
+                    continue
                 seq.append(I(self.mfma, A_O(qb, db), V_F(db), P_OP(X, qb), A_O(qb, db), tag=f"pv db{db} qb{qb}", **self.fmt) if qb in qbs else None)
             if db & 1:
                 qb = db >> 1
@@ -1160,6 +1203,21 @@ class Gen:
             co = V(V_T[8], 2)      # (an even register: the factor is read as the low word of an aligned 64-bit operand)
             for qb in range(2):
                 l_skip = self.lab("rescale_skip")
+                if self.scaled:
+                    # the row sums take 2^(m_old - m), the new scale byte takes over; O only on the guard path (bit 2 + qb)
+                    l_noo = self.lab("rescale_no_o")
+                    blk += [I("s_bitcmp1_b32", S_FLAG, qb), I("s_cbranch_scc0", Label(l_skip)),
+                            I("v_mov_b32", co.sub(0), V(V_CO[qb])), I("v_mov_b32", V(V_SCL[qb]), V(V_SCP[qb]))]
+                    blk += [I("v_pk_mul_f32", V(V_LACC[qb] + k, 2), V(V_LACC[qb] + k, 2), co, op_sel_hi=(1, 0)) for k in (0, 2)]
+                    blk += [I("v_mov_b32", V(V_CO[qb]), 1.0), I("s_bitcmp1_b32", S_FLAG, 2 + qb), I("s_cbranch_scc0", Label(l_noo)),
+                            I("v_mov_b32", co.sub(0), V(V_CO2[qb]))]
+                    for base in range(0, 64, 8):
+                        regs = [A(qb * 64 + base + k) for k in range(8)]
+                        blk += [I("v_accvgpr_read_b32", tmp[k], regs[k]) for k in range(8)]
+                        blk += [I("v_pk_mul_f32", V(tmp[k].idx, 2), V(tmp[k].idx, 2), co, op_sel_hi=(1, 0)) for k in range(0, 8, 2)]
+                        blk += [I("v_accvgpr_write_b32", regs[k], tmp[k]) for k in range(8)]
+                    blk += [label(l_noo), label(l_skip)]
+                    continue
                 blk += [I("s_bitcmp1_b32", S_FLAG, qb), I("s_cbranch_scc0", Label(l_skip)), I("v_mov_b32", co.sub(0), V(V_CO[qb]))]
                 for base in range(0, 64, 8):
                     regs = [A(qb * 64 + base + k) for k in range(8)]
@@ -1238,6 +1296,11 @@ class Gen:
             e(I("v_fma_f32", l[qb], -l[qb], inv[qb], 1.0), I("v_add_f32", m2[qb], m2[qb], V(V_MSV[qb])))
         for qb in range(2):
             e(I("v_fma_f32", inv[qb], l[qb], inv[qb], inv[qb]), I(self.cvt, m2[qb], m2[qb], m2[qb]))     # (the low byte: L in fp8)
+        if self.scaled:   # O is relative to m_O, l to m: O / (l 2^(m - m_O)); the next job starts at scale 2^0
+            for qb in range(2):
+                e(I("v_sub_u32", V(V_SCP[qb]), 127, V(V_SCL[qb])))
+            for qb in range(2):
+                e(I("v_ldexp_f32", inv[qb], inv[qb], V(V_SCP[qb])), I("v_mov_b32", V(V_SCL[qb]), 127))
         e(self.stamp_async(0))
         # O: 4 accumulators (four consecutive columns of one query) -> one register of four fp8 -> ds_write_b32 at (row i, byte
         # 32 db + 8 g4 + 4 h); one query block at a time.  (S[0] already holds the next job's first scores and v[128:159] its K(1):
@@ -1542,3 +1605,10 @@ def product_gens():
         g.build()
         out.append(g)
     return out
+
+
+def variant_gens():
+    """experiments build: the kernel without the block scale (a rescale of O whenever the running maximum moves) for A/B runs"""
+    g = Gen("e4m3", False, scaled=False)
+    g.build()
+    return [g]

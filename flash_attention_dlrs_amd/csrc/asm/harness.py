@@ -10,7 +10,7 @@ from .fa2_a64_gen import KARG_SIZE, Gen
 
 LOG2E = 1.4426950408889634
 # deferral threshold of the running maximum (log2 units) the launcher passes (fa2_a64.hip): P <= 2^thr; f16 P must stay below 65 504
-A64_THR = {"bf16": 60.0, "f16": 15.875, "e4m3": 6.0, "e5m2": 6.0}      # (fp8: fa2_mfma8x.hip's kThr, P <= 2^6)
+A64_THR = {"bf16": 60.0, "f16": 15.875, "e4m3": 8.5, "e5m2": 15.0}     # (fp8: P <= 2^8.5 inside e4m3's 448, 2^15 inside e5m2's 57 344)
 ESIZE = {"bf16": 2, "f16": 2, "e4m3": 1, "e5m2": 1}
 
 

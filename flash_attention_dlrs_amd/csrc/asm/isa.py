@@ -109,7 +109,10 @@ def fmt_operand(o) -> str:
 
 # opcode classes (for the hazard checker and the issue-cost model)
 MFMA_OPS = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16",
-            "v_mfma_f32_32x32x64_f8f6f4", "v_mfma_f32_16x16x128_f8f6f4"}
+            "v_mfma_f32_32x32x64_f8f6f4", "v_mfma_f32_16x16x128_f8f6f4",
+            # block-scaled form: D = C + (A 2^(sa - 127)) (B 2^(sb - 127)), sa / sb = a byte of the two trailing VGPR operands (E8M0,
+            # one per lane: its row / column); op_sel / op_sel_hi [a, b, 0] pick the byte (bit 0 / bit 1 of its index)
+            "v_mfma_scale_f32_32x32x64_f8f6f4"}
 TRANS_OPS = {"v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"}
 DS_OPS = {"ds_read_b128", "ds_read_b64_tr_b16", "ds_read_b64_tr_b8", "ds_write_b64", "ds_read_b64", "ds_write_b128", "ds_read_b32", "ds_write_b32"}
 VMEM_OPS = {"global_store_dwordx2", "buffer_load_dwordx4", "buffer_store_dwordx4", "buffer_store_short", "buffer_store_dword", "global_store_dword",
@@ -201,7 +204,7 @@ class Inst:
         if op.startswith("s_load_") or op in ("s_memtime", "s_memrealtime"):
             return R(o[0]), (R(o[1]) if len(o) > 1 else [])
         if self.is_mfma:
-            return R(o[0]), R(o[1]) + R(o[2]) + R(o[3])
+            return R(o[0]), [r for x in o[1:] for r in R(x)]
         if op.startswith("ds_read"):
             return R(o[0]), R(o[1])
         if op.startswith("ds_write"):

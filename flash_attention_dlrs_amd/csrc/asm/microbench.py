@@ -35,6 +35,8 @@ class MB:
         for k in range(0, 256, 1):
             e(I("v_accvgpr_write_b32", A(k), 0))
         e(I("v_mov_b32", V(203), 0.25))
+        for k in (208, 209, 210):
+            e(I("v_mov_b32", V(k), 0x7F7F7F7F))      # scale bytes 127 = 2^0
         e(waitcnt(lgkmcnt=0))
         # buffer descriptor of the source buffer
         e(I("s_mov_b32", S(8), S(6)))
@@ -57,7 +59,10 @@ class MB:
                 acc = A(0, 16) if agpr_c else V(0, 16)
             else:
                 acc = A(16 * u, 16) if agpr_c else V(16 * (u % 4), 16)
-            if mfma and f8:     # the 64-cycle fp8 form of the a8 kernel (operands of 8 registers)
+            if mfma and f8 == "scale":     # ... its block-scaled form (two more VGPR operands: the lanes' E8M0 scale bytes)
+                e(I("v_mfma_scale_f32_32x32x64_f8f6f4", acc, V(128 + 8 * (u % 4), 8), V(160 + 8 * (u % 4), 8), acc, V(208), V(209 + (u & 1)),
+                    op_sel_hi=(0, 0, 0)))
+            elif mfma and f8:     # the 64-cycle fp8 form of the a8 kernel (operands of 8 registers)
                 e(I("v_mfma_f32_32x32x64_f8f6f4", acc, V(128 + 8 * (u % 4), 8), V(160 + 8 * (u % 4), 8), acc))
             elif mfma:
                 e(I("v_mfma_f32_32x32x16_bf16", acc, V(128 + 8 * (u % 4), 4), V(160 + 4 * (u % 4), 4), acc))
@@ -154,6 +159,8 @@ def cases():
     }
     for nm, pat in f8pats.items():
         out.append(MB(f"mb8_{nm}", (lambda u, pat=pat: [f(u, k) for k, f in enumerate(pat)]), f8=True))
+    for nm in ("none", "e4", "e8", "f8", "mix_il", "mix_il_x2"):
+        out.append(MB(f"mb8s_{nm}", (lambda u, pat=f8pats[nm]: [f(u, k) for k, f in enumerate(pat)]), f8="scale"))
     # no MFMA at all (the epilogue's regime): cycles per group of 8 instructions -> / 8 = cycles per instruction
     ACR = lambda u, k: I("v_accvgpr_read_b32", V(r(u, k)), A(16 * u + k))
     MUL = lambda u, k: I("v_mul_f32", V(r(u, k)), V(r(u, k)), V(203))

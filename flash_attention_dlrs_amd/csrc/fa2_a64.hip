@@ -215,7 +215,7 @@ int launch(const Fa2Problem &p, int shape16) {
     // 24 still fired a few times per job and wave -- measured 3 443 vs 2 946 cycles per tile step.  f16 P must stay below 65504.
     // (2^15.875 = 60 097 < 65 504; 12 -> 15.875: +3..4 % on the reference bench's fp16 shape, fewer rescales)
     a.thr = p.dtype == FA2_DTYPE_F16 ? 15.875f : 60.0f;
-    if (f8) a.thr = 6.0f;      // (P <= 2^6 stays far inside e4m3's 448; fa2_mfma8x.hip's kThr)
+    if (f8) a.thr = p.dtype == FA2_DTYPE_F8E4M3 ? 8.5f : 15.0f;      // (P <= 2^8.5 inside e4m3's 448, 2^15 inside e5m2's 57 344; fa2_mfma8x.hip's)
     a.group = 1;
     if (p.causal && (a.nbh & 7) == 0) {
         const int per_xcd = a.nbh / 8;

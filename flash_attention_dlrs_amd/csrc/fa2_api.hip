@@ -130,12 +130,12 @@ int pick_variant(const Fa2Problem &p) {
         // shape (N = 4096), +4 % (N = 2048), +2.6 % (N = 8192), +2.5 % (N = 16384), +2.4 % (d = 64).
         return FA2_VARIANT_MFMA16H;
     }
-    // (The generated fp8 kernel A8 -- asm/fa2_a8_gen.py: the A64 structure on v_mfma_f32_32x32x64_f8f6f4, bit-identical to MFMA8X --
-    // is NOT the default: which of the two is faster depends on the data.  BASELINE configs[4]'s per-GPU shard (B16 H8 N16384), same
-    // device: inputs N(0, 0.25), scores of sigma 4 log2 units: A8 2 266 .. 2 309 vs 2 164 .. 2 191 TFLOP/s (+5 %); inputs N(0, 1) as
-    // SURVEY section 8d draws them, sigma 16: the running maximum passes the 6-unit deferral threshold of fp8 P in a quarter of the
-    // tile steps, and a rescale of O costs the one wave of a SIMD ~900 cycles with nothing else to run there: A8 2 080 vs 2 216.
-    // profiles/r03/a8_vs_mfma8x.jsonl.  FA2_AUTOTUNE=1 times both on the caller's tensors.)
+    // (The generated fp8 kernel A8 -- asm/fa2_a8_gen.py: the A64 structure on v_mfma_f32_32x32x64_f8f6f4 -- in its first form rescaled
+    // O whenever the running maximum moved, like MFMA8X: with one wave per SIMD that cost ~900 cycles per rescale with three waves
+    // waiting, and on N(0, 1) inputs (scores of sigma 16 log2 units against fp8's few units of deferral) it lost to the 8-wave kernel,
+    // 2 080 vs 2 216 TFLOP/s on BASELINE configs[4]'s shard.  Its P.V now runs on the BLOCK-SCALED MFMA: the running maximum is an
+    // integer and the power of two rides in P's E8M0 scale operand, O is never touched: 2 457 vs 2 260 on N(0, 1), 2 418 vs 2 231 on
+    // N(0, 1/4) (profiles/r03/a8_scaled_vs_mfma8x.jsonl); grids: benchmarks/mid_grid_fp8.py, profiles/r03/mid_grid_fp8_a8.jsonl)
     if (fa2_mfma8x_supports(p)) {
         // fp8: the double-rate k = 64 MFMA (64-key units).  Against MFMA8 (32x32x16 fp8, the bf16 rate) on MI355X:
         // +26 % at the c5 per-GPU shape (N = 16384 non-causal: 1 880 vs 1 492 TFLOP/s), +19 % at c3 causal.
@@ -147,6 +147,9 @@ int pick_variant(const Fa2Problem &p) {
         const long long jobs = (long long)(p.causal ? (nq256 + 1) / 2 : nq256) * p.B * p.H;
         const double x = (double)jobs / (double)cus;
         const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + cus - 1) / cus) / x <= 1.2;
+        // the generated kernel (non-causal, N a multiple of 256): best or equal on every even grid from 192 jobs on, +5 .. +9 %
+        // from 512 jobs on; at 1.5 jobs per CU (384) its whole-job steps lose 10 % to the 4-wave kernel like the 8-wave one's
+        if (fa2_a8_supports(p) && wg256 >= T(192) && even) return FA2_VARIANT_A8;
         return wg256 >= T(160) && even ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
     }
     if (fa2_mfma32_supports(p)) return FA2_VARIANT_MFMA32;

@@ -165,7 +165,7 @@ int fa2_oracle_fwd(const float *Q, const float *K, const float *V, float *O, flo
 int fa2_oracle_fwd_deferred(const float *Q, const float *K, const float *V, float *O, float *L,
                             const int64_t qs[4], const int64_t ks[4], const int64_t vs[4],
                             const int64_t os[4], const int64_t ls[2], int B, int H, int N, int d, int dtype,
-                            int causal, float scale, int G, int B_c, float thr, int sum_rounded) {
+                            int causal, float scale, int G, int B_c, float thr, int sum_rounded, int ceil_m) {
     if (!Q || !K || !V || !O || !L || B <= 0 || H <= 0 || N <= 0 || d <= 0 || G <= 0 || B_c <= 0) return -1;
     const float c_log2e = (float)((double)scale * LOG2_E);
     float *S = (float *)malloc(sizeof(float) * (size_t)G * B_c);
@@ -209,7 +209,10 @@ int fa2_oracle_fwd_deferred(const float *Q, const float *K, const float *V, floa
                     for (int r = 0; r < rows; ++r) {
                         float *o = Oi + (size_t)r * d;
                         if (fire || thr < 0.0f) {
-                            const float m_new = m[r] > mx[r] ? m[r] : mx[r];
+                            /* ceil_m: the block-scaled fp8 kernel (fa2_a8_gen.py) keeps the running maximum an integer, so that
+                             * every factor is an exact power of two and O is scaled through the MFMA's block scale instead */
+                            const float mxr = ceil_m ? ceilf(mx[r]) : mx[r];
+                            const float m_new = m[r] > mxr ? m[r] : mxr;
                             const float coeff = exp2f(m[r] - m_new);
                             l[r] *= coeff;
                             for (int x = 0; x < d; ++x) o[x] *= coeff;

@@ -49,7 +49,7 @@ def lib():
             [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
         _lib.fa2_oracle_fwd_deferred.restype = ctypes.c_int
         _lib.fa2_oracle_fwd_deferred.argtypes = [fp, fp, fp, fp, fp, i64p, i64p, i64p, i64p, i64p] + \
-            [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+            [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int]
         _lib.fa2_oracle_fwd_f64.restype = ctypes.c_int
         _lib.fa2_oracle_fwd_f64.argtypes = [dp, dp, dp, dp, dp, i64p, i64p, i64p, i64p, i64p] + \
             [ctypes.c_int] * 5 + [ctypes.c_double]
@@ -97,7 +97,7 @@ def forward(Q, K, V, dtype="float32", causal=False, scale=1.0, B_r=16, B_c=16):
     return O, L
 
 
-def forward_deferred(Q, K, V, dtype, causal=False, scale=1.0, G=32, B_c=64, thr=60.0, sum_rounded=True):
+def forward_deferred(Q, K, V, dtype, causal=False, scale=1.0, G=32, B_c=64, thr=60.0, sum_rounded=True, ceil_m=False):
     """fa2_oracle_fwd_deferred: the restatement with the MFMA kernels' deferred running maximum (per G-row group, threshold
     thr in log2 units), the single-rounding exp2(fma(S, c, -m)) and row sums of the rounded P.  Any N."""
     dt = DTYPE_NAMES[dtype] if isinstance(dtype, str) else int(dtype)
@@ -108,7 +108,7 @@ def forward_deferred(Q, K, V, dtype, causal=False, scale=1.0, G=32, B_c=64, thr=
     p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
     rc = lib().fa2_oracle_fwd_deferred(p(Q), p(K), p(V), p(O), p(L), _strides(Q), _strides(K), _strides(V), _strides(O),
                                        (ctypes.c_int64 * 2)(H * N, N), B, H, N, d, dt, int(bool(causal)), float(scale),
-                                       int(G), int(B_c), float(thr), int(bool(sum_rounded)))
+                                       int(G), int(B_c), float(thr), int(bool(sum_rounded)), int(bool(ceil_m)))
     if rc != 0:
         raise ValueError(f"fa2_oracle_fwd_deferred rc={rc}")
     return O, L

@@ -1,8 +1,9 @@
 """CPU tests of the generated fp8 kernel (variant a8, asm/fa2_a8_gen.py: the a64 structure on v_mfma_f32_32x32x64_f8f6f4) -- no GPU.
 
 Wait-state check, assembly for gfx950, and the emulator (fp8 MFMAs, v_cvt_pk_fp8_f32 / _bf8_, ds_read_b64_tr_b8 with the lane map
-measured in round 1) against the CPU oracle IN ITS DEFERRED-MAXIMUM MODE (oracle.forward_deferred(G=32, B_c=64, thr=6, rounded row
-sums): the liberties fa2_mfma8x.hip takes and this kernel shares) -- element by element: >= 99 % of O and 97 % of L bit-identical,
+measured in round 1, the block-scaled MFMA as probed in round 3) against the CPU oracle IN ITS DEFERRED-MAXIMUM MODE
+(oracle.forward_deferred(G=32, B_c=64, thr, rounded row sums; ceil_m for the block-scaled kernel, whose running maximum is an
+integer): the liberties fa2_mfma8x.hip takes and this kernel shares -- element by element: >= 99 % of O and 97 % of L bit-identical,
 the rest within one fp8 step plus half a step of P times max |V| (the bar of tests/test_fwd_parity.py for fa2_mfma8x).
 """
 import os
@@ -20,11 +21,11 @@ ORACLE_DT = {"e4m3": "float8_e4m3fn", "e5m2": "float8_e5m2"}
 _PROGS = {}
 
 
-def prog(dtype):
-    if dtype not in _PROGS:
-        g = Gen(dtype, False)
-        _PROGS[dtype] = (g, g.build())
-    return _PROGS[dtype]
+def prog(dtype, scaled=True):
+    if (dtype, scaled) not in _PROGS:
+        g = Gen(dtype, False, scaled=scaled)
+        _PROGS[dtype, scaled] = (g, g.build())
+    return _PROGS[dtype, scaled]
 
 
 @pytest.mark.parametrize("dtype", ["e4m3", "e5m2"])
@@ -42,15 +43,15 @@ def test_generated_module_assembles_for_gfx950(tmp_path):
     assert KARG_SIZE == 192
 
 
-def _run(oracle, dtype, B, H, N, seed=0, spread=0.5, spike=False, **kw):
+def _run(oracle, dtype, B, H, N, seed=0, spread=0.5, spike=False, scaled=True, **kw):
     rng = np.random.default_rng(seed)
     Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) * spread for _ in range(3))
-    if spike:   # one row's maximum jumps far beyond the deferral threshold (6 log2 units) in the last tile
-        K[:, :, N - 40] = 2.0 * Q[:, :, 5]
-    O, L, _ = harness.run(prog(dtype)[1], Q, K, V, dtype=dtype, causal=False, **kw)
+    if spike:   # one row's maximum jumps far beyond the deferral threshold in the last tile (spike = the factor on the row's own q)
+        K[:, :, N - 40] = float(spike) * Q[:, :, 5]
+    O, L, _ = harness.run(prog(dtype, scaled)[1], Q, K, V, dtype=dtype, causal=False, **kw)
     rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
     O_ref, L_ref = oracle.forward_deferred(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=False, G=32, B_c=64,
-                                           thr=kw.get("thr_override", 6.0), sum_rounded=True)
+                                           thr=kw.get("thr_override", harness.A64_THR[dtype]), sum_rounded=True, ceil_m=scaled)
     L_ref = L_ref.reshape(L.shape)
     assert not np.isnan(O).any()
     step = 0.25 if dtype == "e5m2" else 0.125
@@ -71,8 +72,20 @@ def test_emulated_kernel_job_stream_and_wave_order(oracle):
 
 def test_emulated_steady_loop_and_rescale_path(oracle):
     _run(oracle, "e4m3", 1, 1, 1024, seed=3)
-    _run(oracle, "e4m3", 1, 1, 512, spike=True, seed=2)
-    _run(oracle, "e5m2", 1, 2, 512, nwg=1, seed=4, spread=1.0)        # (scores of sigma 16 log2 units: the rescale path in most steps)
+    _run(oracle, "e4m3", 1, 1, 512, spike=2.0, seed=2)
+    _run(oracle, "e5m2", 1, 2, 512, nwg=1, seed=4, spread=1.0)        # (scores of sigma 16 log2 units: the maximum moves in most steps)
+    _run(oracle, "e4m3", 1, 1, 512, seed=5, spread=1.0, thr_override=6.0)
+
+
+def test_emulated_guard_path_rebases_the_accumulators(oracle):
+    """m - m_O beyond KMAX = 64 log2 units: the spike row's score is ~ 8 |q|^2 = several hundred"""
+    _run(oracle, "e4m3", 1, 1, 512, spike=8.0, seed=2)
+
+
+def test_emulated_kernel_without_the_block_scale(oracle):
+    """the A/B variant of the experiments build: O is rescaled whenever the running maximum moves (round 3's first form)"""
+    _run(oracle, "e4m3", 1, 1, 512, spike=2.0, seed=2, scaled=False)
+    _run(oracle, "e4m3", 1, 1, 256, seed=7, spread=1.0, scaled=False, thr_override=6.0)
 
 
 def test_tile_images_are_conflict_free_for_operand_reads(monkeypatch):

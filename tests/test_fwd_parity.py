@@ -397,53 +397,74 @@ def test_golden_fp8_e5m2_on_the_gpu(oracle):
     assert (O - exact).abs().mean() <= (O_gold - exact).abs().mean()
 
 
+FP8_THR = {torch.float8_e4m3fn: 8.5, torch.float8_e5m2: 15.0}    # deferral threshold of the running maximum (fa2_mfma8x.hip, fa2_a64.hip)
+
+
+def _fp8_close(O, L, O_ref, L_ref, V, step, same_o=0.99, same_l=0.97):
+    O, L, O_ref, L_ref = O.float(), L.float().flatten(), O_ref.float(), L_ref.float().flatten()
+    assert (O == O_ref).float().mean() >= same_o and (L == L_ref).float().mean() >= same_l, ((O == O_ref).float().mean(), (L == L_ref).float().mean())
+    assert ((O - O_ref).abs() <= step * O_ref.abs() + 0.5 * step * V.float().abs().max()).all()
+    assert ((L - L_ref).abs() <= step * L_ref.abs() + 1e-3).all()
+
+
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 def test_generated_fp8_kernel_a8(oracle, dtype):
-    """the generated fp8 kernel (variant a8, asm/fa2_a8_gen.py: the a64 structure on v_mfma_f32_32x32x64_f8f6f4; non-causal, N a
-    multiple of 256): element by element against the oracle's deferred-maximum mode -- the bar of fa2_mfma8x below -- bit-identical
-    to fa2_mfma8x (same liberties, same order), several jobs per workgroup, (B, N, H, d)-strided inputs, and the table's choice"""
+    """the generated fp8 kernel (variant a8, asm/fa2_a8_gen.py: the a64 structure on v_mfma_f32_32x32x64_f8f6f4 with P.V on its
+    block-scaled form; non-causal, N a multiple of 256): element by element against the oracle's deferred-maximum mode with an
+    INTEGER running maximum (ceil_m: the kernel never rescales O, the power of two rides in the MFMA's scale operand) -- the bar of
+    fa2_mfma8x below; against fa2_mfma8x itself (whose maximum is not rounded up: P is rounded against another reference) within
+    the same bound; several jobs per workgroup, narrow and N(0, 1) inputs (the maximum moves in most steps), (B, N, H, d)-strided
+    inputs, the guard path (a row's maximum jumps by several hundred log2 units) and the table's choice"""
     step = 0.25 if dtype == torch.float8_e5m2 else 0.125
-    u8 = lambda t: t.contiguous().view(torch.uint8)
-    for shape, seed in (((1, 2, 256, 128), 5), ((2, 3, 512, 128), 6), ((1, 5, 1024, 128), 7), ((3, 120, 768, 128), 8)):
-        Q, K, V = _rand(shape, dtype, seed=seed, spread=0.5)
+    f = lambda t: t.float().numpy()
+    for shape, seed, spread in (((1, 2, 256, 128), 5, 0.5), ((2, 3, 512, 128), 6, 0.5), ((1, 5, 1024, 128), 7, 1.0), ((3, 120, 768, 128), 8, 0.5),
+                                ((1, 2, 2048, 128), 9, 1.0)):
+        Q, K, V = _rand(shape, dtype, seed=seed, spread=spread)
         O, L = hip_forward(Q, K, V, variant="a8")
         O8, L8 = hip_forward(Q, K, V, variant="mfma8x")
-        assert torch.equal(u8(O), u8(O8)) and torch.equal(u8(L), u8(L8)), shape
+        _fp8_close(O, L, O8, L8, V, step, same_o=0.5, same_l=0.9)    # (two valid roundings of P: 60-85 % of O equal between the oracle's two modes)
         if shape[0] * shape[1] <= 6:
-            f = lambda t: t.float().numpy()
-            O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=False, G=32, B_c=64, thr=6.0, sum_rounded=True)
-            O, L, O_ref, L_ref = O.float(), L.float().flatten(), torch.from_numpy(O_ref), torch.from_numpy(L_ref).flatten()
-            assert (O == O_ref).float().mean() >= 0.99 and (L == L_ref).float().mean() >= 0.97
-            assert ((O - O_ref).abs() <= step * O_ref.abs() + 0.5 * step * V.float().abs().max()).all()
+            O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=False, G=32, B_c=64, thr=FP8_THR[dtype],
+                                                   sum_rounded=True, ceil_m=True)
+            _fp8_close(O, L, torch.from_numpy(O_ref), torch.from_numpy(L_ref), V, step)
+    Q, K, V = _rand((1, 2, 512, 128), dtype, seed=10, spread=0.5)
+    K[:, :, 500] = (Q[:, :, 7].float() * 8.0).to(dtype)     # row 7's score against key 500: ~ 8 |q|^2 = 256 -> m - m_O far beyond KMAX = 64
+    O, L = hip_forward(Q, K, V, variant="a8")
+    O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=False, G=32, B_c=64, thr=FP8_THR[dtype], sum_rounded=True, ceil_m=True)
+    assert torch.isfinite(O.float()).all()
+    _fp8_close(O, L, torch.from_numpy(O_ref), torch.from_numpy(L_ref), V, step)
+    u8 = lambda t: t.contiguous().view(torch.uint8)
     gen = torch.Generator().manual_seed(9)
     Q, K, V = ((torch.randn(2, 512, 3, 128, generator=gen) * 0.5).to(dtype).transpose(1, 2) for _ in range(3))     # row stride 3 * 128 bytes
     O, L = hip_forward(Q, K, V, variant="a8")
-    O8, L8 = hip_forward(Q, K, V, variant="mfma8x")
-    assert torch.equal(u8(O), u8(O8)) and torch.equal(u8(L), u8(L8))
+    O2, L2 = hip_forward(Q.contiguous(), K.contiguous(), V.contiguous(), variant="a8")
+    assert torch.equal(u8(O), u8(O2)) and torch.equal(u8(L), u8(L2))
     x = torch.zeros(1, 2, 320, 128).to(dtype)
     with pytest.raises(TypeError):
         hip_forward(x, x, x, variant="a8")                 # N not a multiple of 256
     with pytest.raises(TypeError):
         hip_forward(Q, K, V, causal=True, variant="a8")    # no causal form
     en = fa.convert_triton_dtype(dtype)
-    # (not the table's choice: on N(0, 1) inputs -- scores of sigma 16 log2 units against fp8's 6-unit deferral threshold -- the
-    # 8-wave kernel is faster; pick_variant() in csrc/fa2_api.hip has the numbers)
-    assert _lib.query_tile(16384, 128, en, False, B=16, H=8)[0] == _lib.VARIANT_MFMA8X
+    # the table's choice on large even grids (pick_variant() in csrc/fa2_api.hip has the numbers); 1.5 jobs per CU and small grids stay
+    assert _lib.query_tile(16384, 128, en, False, B=16, H=8)[0] == _lib.VARIANT_A8
+    assert _lib.query_tile(2048, 128, en, False, B=1, H=48)[0] == _lib.VARIANT_MFMA8X_W4
+    assert _lib.query_tile(2048, 128, en, False, B=1, H=16)[0] in (_lib.VARIANT_MFMA8X, _lib.VARIANT_MFMA8X_W4)
+    assert _lib.query_tile(16384, 128, en, True, B=16, H=8)[0] == _lib.VARIANT_MFMA8X
 
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("variant", ["mfma8x", "mfma8x_w4"])
 def test_fp8_mfma_kernel_element_wise_against_the_oracle_in_deferred_maximum_mode(oracle, dtype, causal, variant):
-    """fa2_mfma8x keeps the running maximum of a wave's 32 rows while none of them exceeds it by 6 log2 units within a 64-key
-    unit, forms exp2(fma(S, c, -m)) and sums the rounded P on the matrix pipe: exactly oracle.forward_deferred(G=32, B_c=64,
-    thr=6).  Against that restatement, element by element: >= 99 % of O bit-identical (a systematic one-ulp bias would fail
+    """fa2_mfma8x keeps the running maximum of a wave's 32 rows while none of them exceeds it by 8.5 (e4m3) / 15 (e5m2) log2 units
+    within a 64-key unit, forms exp2(fma(S, c, -m)) and sums the rounded P on the matrix pipe: exactly oracle.forward_deferred(G=32,
+    B_c=64, thr).  Against that restatement, element by element: >= 99 % of O bit-identical (a systematic one-ulp bias would fail
     this bar); an element that differs is off by its own rounding step plus at most one rounding step of P times max |V| (a P
     that v_exp_f32's last bit rounds the other way moves O by its share p / l of V)."""
     for shape, seed in (((2, 2, 320, 128), 5), ((1, 3, 191, 128), 6), ((1, 2, 1024, 128), 7)):
         Q, K, V = _rand(shape, dtype, seed=seed, spread=0.5)
         f = lambda t: t.float().numpy()
-        O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64, thr=6.0,
+        O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64, thr=FP8_THR[dtype],
                                                sum_rounded=True)
         O, L = hip_forward(Q, K, V, causal=causal, variant=variant)
         O, L, O_ref, L_ref = O.float(), L.float().flatten(), torch.from_numpy(O_ref), torch.from_numpy(L_ref).flatten()
@@ -491,14 +512,16 @@ def test_fp8_c5_head_shard_properties():
     dtype, B, H, N, d = torch.float8_e4m3fn, 1, 8, 16384, 128
     torch.manual_seed(42)
     Q, K, V = ((torch.randn(B, H, N, d, device=DEV) * 0.5).to(dtype) for _ in range(3))
-    assert _lib.query_tile(N, d, _lib.FA2_DTYPE_F8E4M3, False)[0] == _lib.VARIANT_MFMA8X
-    O, L = fa.flash_attention_forward(Q, K, V, DEV)
-    O2, L2 = fa.flash_attention_forward(Q, K, V, DEV)
+    # the kernel the table picks for a GPU's whole shard (B16 H8: 8 192 jobs) -- pinned, because this slice's two-head pieces are
+    # grids of their own (128 jobs) for which the table would pick another kernel: equal bits need the same kernel
+    assert _lib.query_tile(N, d, _lib.FA2_DTYPE_F8E4M3, False, B=16, H=8)[0] == _lib.VARIANT_A8
+    run = lambda q, k, v: fa.flash_attention_forward(q, k, v, DEV, variant="a8")
+    O, L = run(Q, K, V)
+    O2, L2 = run(Q, K, V)
     assert torch.equal(O.view(torch.uint8), O2.view(torch.uint8)) and torch.equal(L.view(torch.uint8), L2.view(torch.uint8))
-    parts = [fa.flash_attention_forward(Q[:, h0:h0 + 2].contiguous(), K[:, h0:h0 + 2].contiguous(),
-                                        V[:, h0:h0 + 2].contiguous(), DEV)[0] for h0 in range(0, H, 2)]
+    parts = [run(Q[:, h0:h0 + 2].contiguous(), K[:, h0:h0 + 2].contiguous(), V[:, h0:h0 + 2].contiguous())[0] for h0 in range(0, H, 2)]
     assert torch.equal(torch.cat(parts, dim=1).view(torch.uint8), O.view(torch.uint8))
-    O1, _ = fa.flash_attention_forward(Q, K, torch.ones(B, H, N, d, device=DEV).to(dtype), DEV)
+    O1, _ = run(Q, K, torch.ones(B, H, N, d, device=DEV).to(dtype))
     assert (O1.float() == 1).all()
     assert torch.isfinite(O.float()).all() and torch.isfinite(L.float()).all()
     # one (b, h) against the exact attention of the fp8 inputs (fp64 on the GPU), statistical bars of the fp8 tests
