@@ -125,14 +125,14 @@ S_FIRE = (S(0, 2), S(2, 2))      # per query block: lanes whose row maximum pass
 S_X2 = S(82)
 
 # LDS map (bytes)
-KB = (0, 8192)
-VBASE = 16384
-VB = (0, 8192)                   # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
-EPI = 32768                      # + 16384 * wave: the wave's private slice: the next job's 64 Q rows land here by LDS-DMA (8 KiB,
+KB = (0, 8192, 16384, 24576)     # rings of up to four 8-KiB buffers (Gen.R of them are used)
+VBASE = 32768
+VB = (0, 8192, 16384, 24576)     # relative to VBASE (folded into the V read lane bases; absolute for the DMA)
+EPI = 65536                      # + 16384 * wave: the wave's private slice: the next job's 64 Q rows land here by LDS-DMA (8 KiB,
                                  # K-tile image) on their way to a[128:159]; later the job's O rows leave through it
 EPI_ROW = 136                    # (= 128 + 8) byte stride of an O row in the slice during the epilogue: 8-byte aligned for the
                                  # row read-back, the 4-byte column writes of 32 lanes are 2-way (free for ds_write_b32)
-LDS_TOTAL = 32768 + 4 * 16384
+LDS_TOTAL = 65536 + 4 * 16384
 
 KARG_SIZE = 192
 NSLOT = 24
@@ -1608,7 +1608,10 @@ def product_gens():
 
 
 def variant_gens():
-    """experiments build: the kernel without the block scale (a rescale of O whenever the running maximum moves) for A/B runs"""
-    g = Gen("e4m3", False, scaled=False)
-    g.build()
-    return [g]
+    """experiments build: the kernel without the block scale (a rescale of O whenever the running maximum moves), and ring depths,
+    for A/B runs"""
+    out = [Gen("e4m3", False, scaled=False), Gen("e4m3", False, name="fa2_fwd_a8_e4m3_n_ring4", ring=(4, 4, 3)),
+           Gen("e4m3", False, name="fa2_fwd_a8_e4m3_n_ring2", ring=(2, 3, 2))]
+    for g in out:
+        g.build()
+    return out
