@@ -227,6 +227,8 @@ class Inst:
             return R(o[0]), R(o[1])
         if op in ("v_cvt_pk_fp8_f32", "v_cvt_pk_bf8_f32"):
             return R(o[0]), R(o[0]) + R(o[1]) + R(o[2])
+        if op in ("v_cvt_scalef32_pk_fp8_f32", "v_cvt_scalef32_pk_bf8_f32"):     # (gfx950; the fourth operand: the scale, an f32)
+            return R(o[0]), R(o[0]) + R(o[1]) + R(o[2]) + R(o[3])
         # generic: first operand is the destination
         if op.startswith("v_") or op.startswith("s_"):
             d = R(o[0])

@@ -146,11 +146,15 @@ def cases():
     # beside the 64-cycle fp8 MFMA (a8): unit costs and orderings of a run of the step's fillers (4 exp, 4 fma, 2 cvt, 2 max3, 1 read)
     C8 = lambda u, k: I("v_cvt_pk_fp8_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), op_sel=(0, 0, k & 1))
     C8D = lambda u, k: I("v_cvt_pk_fp8_f32", V(r(u, 0)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), op_sel=(0, 0, k & 1))   # same destination
+    CS8 = lambda u, k: I("v_cvt_scalef32_pk_fp8_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), 1.0, op_sel=(0, 0, 0, k & 1))
+    CH8 = lambda u, k: I("v_cvt_scalef32_pk_fp8_f16", V(r(u, k)), V(r(u, (k + 1) % 8)), 1.0)
+    CHF = lambda u, k: I("v_cvt_pk_f16_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)))
     TR8 = lambda u, k: I("ds_read_b64_tr_b8", V(64 + 2 * ((8 * u + k) % 16), 2), V(201), offset=512 * ((8 * u + k) % 32))
     f8pats = {
         "none": [], "e4": [EXP] * 4, "e8": [EXP] * 8, "e12": [EXP] * 12, "f8": [FMA] * 8, "f12": [FMA] * 12, "f16": [FMA] * 16,
         "c4": [C8] * 4, "c8": [C8] * 8, "c12": [C8] * 12, "c8d": [C8D] * 8, "cb8": [CVT] * 8, "m8": [MX3] * 8, "m12": [MX3] * 12,
-        "t4": [TR8] * 4, "t8": [TR8] * 8,
+        "t4": [TR8] * 4, "t8": [TR8] * 8, "cs4": [CS8] * 4, "cs8": [CS8] * 8, "cs12": [CS8] * 12, "ch8": [CH8] * 8, "chf8": [CHF, CH8] * 4,
+        "mix_il_cs": [TR8, EXP, FMA, CS8, MX3, EXP, FMA, EXP, FMA, CS8, EXP, FMA, MX3],
         "mix_il": [TR8, EXP, FMA, C8, MX3, EXP, FMA, EXP, FMA, C8, EXP, FMA, MX3],
         "mix_grp": [TR8, EXP, EXP, EXP, EXP, FMA, FMA, FMA, FMA, C8, C8, MX3, MX3],
         "mix_il_nocv": [TR8, EXP, FMA, MX3, EXP, FMA, EXP, FMA, EXP, FMA, MX3],
