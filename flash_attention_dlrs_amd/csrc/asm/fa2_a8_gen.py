@@ -58,6 +58,8 @@ V_SCL = (234, 235)        # the E8M0 scale byte (byte 0) of the P operands whose
 V_SCP = (236, 237)        # ... the one that takes over at the end of this phase B (a decision of the tile that starts)
 V_CO2 = (238, 239)        # guard path (m - m_O would pass KMAX): the factor 2^-(m - m_O) that re-bases O
 V_S127 = 240              # the scale byte of the V^T operand: 127 = 2^0
+V_IMH = 241               # causal: i - 4 h (query row inside a 32-row block minus the lane half's key offset)
+V_PM = (242, 243, 244, 245)   # causal: AND masks of the four packed P registers (four fp8 each) of a triangle group
 KMAX = 64                 # largest m - m_O before O is re-based: 2^(64 + 8.5) N max|V| stays far inside fp32, 2^-64 / l above its denormals
 
 
@@ -141,7 +143,8 @@ NSLOT = 24
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
                  caps=(5, 24), split=True, scaled=True):
-        assert dtype in ("e4m3", "e5m2") and not causal and not ragged, "a8: OCP fp8, non-causal, N a multiple of 256"
+        assert dtype in ("e4m3", "e5m2") and not ragged, "a8: OCP fp8, N a multiple of 256"
+        assert split or not causal, "a8: the causal kernels use the split row map"
         self.dtype = dtype
         # scaled: P.V on v_mfma_scale_f32_32x32x64_f8f6f4.  fp8 P leaves 8.5 log2 units of deferral (e4m3 tops out at 448): on N(0, 1)
         # inputs at scale 1 (scores of sigma 16) a row's maximum passes it in a quarter of the tile steps, and a rescale of 64
@@ -407,6 +410,20 @@ class Gen:
           I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
           I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
+        if self.causal:
+            e(comment("causal: lane constants of the diagonal mask"),
+              I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
+              I("v_sub_u32", V(V_IMH), t0, t3),   # i - 4 h
+              I("v_mov_b32", NINF, float("-inf")))
+            # packed P register p of a triangle group holds, in byte b, the score of key b + 8 p + 4 h of the group's 32 against
+            # query i: kept iff key <= i
+            for p_ in range(4):
+                for b in range(4):
+                    e(I("v_cmp_ge_i32", VCC, V(V_IMH), 8 * p_ + b), I("v_mov_b32", t2, 0xFF << (8 * b)))
+                    if b == 0:
+                        e(I("v_cndmask_b32", V(V_PM[p_]), 0, t2, VCC))
+                    else:
+                        e(I("v_cndmask_b32", t1, 0, t2, VCC), I("v_or_b32", V(V_PM[p_]), V(V_PM[p_]), t1))
 
     # ------------------------------------------------------------------ job decode: S_JOB (+ S_PASS) -> S_NB, S_NHH, S_NQI, S_NNT
     def k_decode_next(self, vt=None):
@@ -508,11 +525,25 @@ class Gen:
         return out + pre + [I("s_nop", 0), ld]
 
     def stream_start(self, which):
-        """start offset of the NEXT job's K / V tile stream (non-causal: tile 0, upwards)"""
-        return [I("s_mov_b32", S_KDMA, S_KW)] if which == "k" else [I("s_mov_b32", S_VDMA, S_VW)]
+        """causal: start offset and step of the NEXT job's K / V tile stream -- upwards from tile 0, or (S_NDESC) downwards from
+        the tile under the diagonal span, 4 qi - 1.  S_K64 / S_V64 hold the signed step of the running stream (fa2_a64_gen.py)"""
+        dma, w0, s32, step = (S_KDMA, S_KW, S_K32, S_K64) if which == "k" else (S_VDMA, S_VW, S_V32, S_V64)
+        if not self.down:
+            return [I("s_mov_b32", dma, w0)]
+        t0, t1 = S_T[6], S_T[7]     # (the 64-bit multiply's scratch: free between scalar units; S_T[2..4] belong to the Q staging)
+        return [I("s_lshl_b32", t0, s32, 1), I("s_lshl_b32", t1, S_NQI, 2), I("s_sub_u32", t1, t1, 1), I("s_mul_i32", t1, t1, t0),
+                I("s_cmp_lg_u32", S_NDESC, 0), I("s_cselect_b32", t1, t1, 0), I("s_add_u32", dma, w0, t1),
+                I("s_sub_u32", t1, 0, t0), I("s_cmp_lg_u32", S_NDESC, 0), I("s_cselect_b32", step, t1, t0)]
 
     def stream_to_diagonal(self, which):
-        return []
+        """causal, the steady loop's last trip: the stream has reached the job's diagonal span -- tiles 4 qi .. 4 qi + 3, upwards"""
+        if not self.down:
+            return []
+        dma, w0, s32, step = (S_KDMA, S_KW, S_K32, S_K64) if which == "k" else (S_VDMA, S_VW, S_V32, S_V64)
+        t0, t1 = S_T[6], S_T[7]
+        return [I("s_lshl_b32", t0, s32, 1), I("s_lshl_b32", t1, S_QI, 2), I("s_mul_i32", t1, t1, t0), I("s_add_u32", t1, t1, w0),
+                I("s_cmp_eq_u32", S_LOOP, 1), I("s_cselect_b32", dma, t1, dma),
+                I("s_cmp_eq_u32", S_LOOP, 1), I("s_cselect_b32", step, t0, step)]
 
     def dma_tile(self, which, buf):
         out = []
@@ -525,7 +556,7 @@ class Gen:
         """Q rows of job (b, hh, qi) of this wave -> the wave's LDS slice by LDS-DMA, in the K-tile image (8 pieces of 8 rows x
         128 bytes).  Returns (descriptor / offset setup, [pieces])"""
         setup = self.make_desc(S_SQ, S_Q, S_QSB, S_QSH, b, hh, S_QSN)
-        setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
+        setup += [I("s_lshl_b32", S_T[0], qi, 8), I("s_lshl_b32", S_T[1], S_WAVE, 5 if self.split else 6), I("s_add_u32", S_T[0], S_T[0], S_T[1]),
                   I("s_mul_i32", S_T[2], S_T[0], S_QSN),                # byte offset of the wave's first row
                   I("s_lshl_b32", S_T[3], S_QSN, 3),                    # 8 rows
                   I("s_lshl_b32", S_T[4], S_WAVE, 14), I("s_add_u32", S_T[4], S_T[4], EPI)]
@@ -535,6 +566,9 @@ class Gen:
             pc = []
             if R:
                 pc.append(I("s_add_u32", S_T[2], S_T[2], S_T[3]))
+            if self.split and R == 4:
+                # split row map: the second query block starts 128 rows behind the first (96 = 12 x 8 rows further on)
+                pc += [I("s_mul_i32", S_X2, S_T[3], 12), I("s_add_u32", S_T[2], S_T[2], S_X2)]
             pc.append(I("s_add_u32", M0, S_T[4], 1024 * R))
             pre, ld = self.buf_op("buffer_load_dwordx4", None, V(V_DQ[R & 1]), S_SQ, S_T[2], lds=1, tag=f"qdma R{R}")
             pieces.append((pc + pre, ld))
@@ -781,6 +815,10 @@ class Gen:
                 # the end of this phase B, where the new scale byte 127 + (m - m_O) becomes the P operands' (this phase's P.V still
                 # runs on the tile that was rounded against the old m).  Guard: m - m_O > KMAX -> O is re-based to m as well
                 l_guard, l_gback = self.lab("guard"), self.lab("guard_back")
+                if exact:    # (a lazily masked diagonal tile: the partial maxima ran over hidden keys too -- with the exact maximum in
+                    #           hand, leave unless a row really passes the threshold, as the oracle's deferred mode decides)
+                    swap = swap + [I("v_fma_f32", t3, a, S_C, -V(V_MC[qb])), I("v_cmp_lt_f32", VCC, S_THR, t3), I("s_nop", 3),
+                                   I("s_cbranch_vccz", Label(l_back))]
                 self.ool.append([label(l_fire)] + exact + swap +
                                 [I("v_mul_f32", t2, S_C, a), I("v_ceil_f32", t2, t2), I("v_max_f32", t2, t2, V(V_MC[qb])),
                                  I("v_sub_f32", t3, V(V_MC[qb]), t2), I("v_mov_b32", V(V_MC[qb]), t2), I("v_exp_f32", V(V_CO[qb]), t3),
@@ -910,14 +948,15 @@ class Gen:
             # visible, key block 1: triangle).  D0 in line, D1 out of line (a taken branch costs what eight VALU operations do)
             assert kind == "pm"
             qa = jd >> 1
-            g0, g1 = 2 * qa, 2 * qa + 1
+            # (fp8: the packed P of score group (qa, kb) is the four registers Sb + 32 qa + 4 kb .. + 3, four keys each)
+            p0, p1 = Sb + 32 * qa, Sb + 32 * qa + 4
             l_d1, l_back, l_skip = self.lab("pmask_d1"), self.lab("pmask_back"), self.lab("pmask_skip")
-            self.ool.append([label(l_d1)] + [I("v_and_b32", V(Sb + 16 * g1 + j), V(Sb + 16 * g1 + j), V(V_PM[j])) for j in range(8)] +
+            self.ool.append([label(l_d1)] + [I("v_and_b32", V(p1 + j), V(p1 + j), V(V_PM[j])) for j in range(4)] +
                             [I("s_branch", Label(l_back))])
             head = [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_skip))] if cond is not None else []
             return head + [I("s_bitcmp1_b32", S_WAVE, 0), I("s_cbranch_scc1", Label(l_d1))] + \
-                [I("v_and_b32", V(Sb + 16 * g0 + j), V(Sb + 16 * g0 + j), V(V_PM[j])) for j in range(8)] + \
-                [I("v_mov_b32", V(Sb + 16 * g1 + j), 0) for j in range(8)] + [label(l_back)] + ([label(l_skip)] if cond is not None else [])
+                [I("v_and_b32", V(p0 + j), V(p0 + j), V(V_PM[j])) for j in range(4)] + \
+                [I("v_mov_b32", V(p1 + j), 0) for j in range(4)] + [label(l_back)] + ([label(l_skip)] if cond is not None else [])
         if kind == "pm":
             l_pm, l_back = self.lab("pmask"), self.lab("pmask_back")
             blk = [label(l_pm)]
@@ -1601,9 +1640,10 @@ def product_gens():
     """the kernels of this generator that ship in libfa2_hip.so's code object (built by fa2_a64_gen.main)"""
     out = []
     for dtype in ("e4m3", "e5m2"):
-        g = Gen(dtype, False)
-        g.build()
-        out.append(g)
+        for causal in (False, True):
+            g = Gen(dtype, causal)
+            g.build()
+            out.append(g)
     return out
 
 

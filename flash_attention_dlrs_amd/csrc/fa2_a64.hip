@@ -40,7 +40,7 @@ struct DevState {
     bool ready = false, failed = false;
     hipModule_t mod = nullptr;
     hipFunction_t fn[2][2][2][2] = {};  // [a64 / a16][bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
-    hipFunction_t fn8[2] = {};          // a8: [e4m3 / e5m2], non-causal, N % 256 == 0
+    hipFunction_t fn8[2][2] = {};       // a8: [e4m3 / e5m2][non-causal / causal], N % 256 == 0
     hipFunction_t fnd[2][2] = {};       // a64d (head size 64): [bf16 / f16][non-causal / causal], N % 256 == 0
     int cus = 0;
 };
@@ -81,10 +81,13 @@ DevState *dev_state() {
                     e = hipModuleGetFunction(&d.fn[m][t][c][r], d.mod, nm);
                     if (e != hipSuccess) d.fn[m][t][c][r] = nullptr;  // a kernel the generator did not emit: reported at launch
                 }
-    for (int t = 0; t < 2; ++t) {
-        e = hipModuleGetFunction(&d.fn8[t], d.mod, t ? "fa2_fwd_a8_e5m2_n" : "fa2_fwd_a8_e4m3_n");
-        if (e != hipSuccess) d.fn8[t] = nullptr;
-    }
+    for (int t = 0; t < 2; ++t)
+        for (int c = 0; c < 2; ++c) {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "fa2_fwd_a8_%s_%s", t ? "e5m2" : "e4m3", c ? "c" : "n");
+            e = hipModuleGetFunction(&d.fn8[t][c], d.mod, nm);
+            if (e != hipSuccess) d.fn8[t][c] = nullptr;
+        }
     for (int t = 0; t < 2; ++t)
         for (int c = 0; c < 2; ++c) {
             char nm[64];
@@ -123,10 +126,10 @@ int launch(const Fa2Problem &p, int shape16);
 }
 
 // fp8: one byte per element, rows of 128 bytes; otherwise the conditions of the 16-bit kernels (16-byte aligned rows and bases,
-// N * row stride below 2 GiB); non-causal, N a multiple of 256 (every other fp8 shape: fa2_mfma8x.hip)
+// N * row stride below 2 GiB); N a multiple of 256 (every other fp8 shape: fa2_mfma8x.hip)
 bool fa2_a8_supports(const Fa2Problem &p) {
     if (p.dtype != FA2_DTYPE_F8E4M3 && p.dtype != FA2_DTYPE_F8E5M2) return false;
-    if (p.d != 128 || p.N < 256 || (p.N & 255) || p.causal) return false;
+    if (p.d != 128 || p.N < 256 || (p.N & 255)) return false;
     if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
     if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
     const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
@@ -179,7 +182,7 @@ int launch(const Fa2Problem &p, int shape16) {
         }
     } else if (f8) {
         if (!fa2_a8_supports(p)) {
-            fa2_set_error("a8 kernel: needs fp8 (e4m3fn / e5m2), d = 128, N a multiple of 256, no mask, unit d-stride, 16-byte aligned rows");
+            fa2_set_error("a8 kernel: needs fp8 (e4m3fn / e5m2), d = 128, N a multiple of 256, unit d-stride, 16-byte aligned rows");
             return FA2_ERR_UNSUPPORTED;
         }
     } else if (!fa2_a64_supports(p)) {
@@ -189,7 +192,7 @@ int launch(const Fa2Problem &p, int shape16) {
     }
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
-    hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0]
+    hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0][p.causal ? 1 : 0]
                      : d64 ? d->fnd[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0]
                            : d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {
@@ -228,7 +231,7 @@ int launch(const Fa2Problem &p, int shape16) {
     // instead of each starting again at tile 0 at a time of its own.  The order is a function of (query block, nq) alone, so a
     // head's result does not depend on the launch it is part of (bit-identical head sharding).  Same-device A/B against
     // FA2_A64_PAIRS=0 (profiles/r03/pairs_ab.jsonl): c3 +1 %, N = 2048 +2.8 %, N >= 8192 0 .. -0.6 % (left alone there).
-    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && (shape16 == 0 || d64);
+    bool down = p.causal && (p.N & 255) == 0 && a.nq >= 2 && a.nq <= 16 && (shape16 == 0 || d64 || f8);
 #ifdef FA2_A64_STAMPS
     down = false;      // (the diagnostic kernels use the registers for the debug pointer)
 #endif

@@ -21,16 +21,17 @@ ORACLE_DT = {"e4m3": "float8_e4m3fn", "e5m2": "float8_e5m2"}
 _PROGS = {}
 
 
-def prog(dtype, scaled=True):
-    if (dtype, scaled) not in _PROGS:
-        g = Gen(dtype, False, scaled=scaled)
-        _PROGS[dtype, scaled] = (g, g.build())
-    return _PROGS[dtype, scaled]
+def prog(dtype, scaled=True, causal=False):
+    if (dtype, scaled, causal) not in _PROGS:
+        g = Gen(dtype, causal, scaled=scaled)
+        _PROGS[dtype, scaled, causal] = (g, g.build())
+    return _PROGS[dtype, scaled, causal]
 
 
 @pytest.mark.parametrize("dtype", ["e4m3", "e5m2"])
-def test_generated_stream_has_no_wait_state_violation(dtype):
-    assert check(prog(dtype)[1], verbose=False) == []
+@pytest.mark.parametrize("causal", [False, True])
+def test_generated_stream_has_no_wait_state_violation(dtype, causal):
+    assert check(prog(dtype, causal=causal)[1], verbose=False) == []
 
 
 def test_generated_module_assembles_for_gfx950(tmp_path):
@@ -38,19 +39,20 @@ def test_generated_module_assembles_for_gfx950(tmp_path):
     if not os.path.exists(clang):
         pytest.skip("no ROCm assembler here")
     src = tmp_path / "a8.s"
-    src.write_text(module_text([prog(dt)[0] for dt in ("e4m3", "e5m2")]))
+    src.write_text(module_text([prog(dt, causal=c)[0] for dt in ("e4m3", "e5m2") for c in (False, True)]))
     subprocess.check_call([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "a8.o")])
     assert KARG_SIZE == 192
 
 
-def _run(oracle, dtype, B, H, N, seed=0, spread=0.5, spike=False, scaled=True, **kw):
+def _run(oracle, dtype, B, H, N, seed=0, spread=0.5, spike=False, scaled=True, causal=False, **kw):
     rng = np.random.default_rng(seed)
     Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) * spread for _ in range(3))
     if spike:   # one row's maximum jumps far beyond the deferral threshold in the last tile (spike = the factor on the row's own q)
         K[:, :, N - 40] = float(spike) * Q[:, :, 5]
-    O, L, _ = harness.run(prog(dtype, scaled)[1], Q, K, V, dtype=dtype, causal=False, **kw)
+    O, L, _ = harness.run(prog(dtype, scaled, causal)[1], Q, K, V, dtype=dtype, causal=causal, **kw)
     rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
-    O_ref, L_ref = oracle.forward_deferred(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=False, G=32, B_c=64,
+    kw.pop("pairs", None)
+    O_ref, L_ref = oracle.forward_deferred(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=causal, G=32, B_c=64,
                                            thr=kw.get("thr_override", harness.A64_THR[dtype]), sum_rounded=True, ceil_m=scaled)
     L_ref = L_ref.reshape(L.shape)
     assert not np.isnan(O).any()
@@ -75,6 +77,14 @@ def test_emulated_steady_loop_and_rescale_path(oracle):
     _run(oracle, "e4m3", 1, 1, 512, spike=2.0, seed=2)
     _run(oracle, "e5m2", 1, 2, 512, nwg=1, seed=4, spread=1.0)        # (scores of sigma 16 log2 units: the maximum moves in most steps)
     _run(oracle, "e4m3", 1, 1, 512, seed=5, spread=1.0, thr_override=6.0)
+
+
+def test_emulated_causal_kernel(oracle):
+    """the causal form (split row map, lazily masked diagonal tiles: byte masks on the packed fp8 P, the exact-maximum check at the
+    head of the firing path), one job, several jobs per workgroup, light jobs walking downwards"""
+    _run(oracle, "e4m3", 1, 1, 256, causal=True)
+    _run(oracle, "e4m3", 1, 3, 768, causal=True, nwg=1, seed=3, spread=0.7)
+    _run(oracle, "e5m2", 1, 1, 1024, causal=True, seed=2, spread=1.0, pairs=True)
 
 
 def test_emulated_guard_path_rebases_the_accumulators(oracle):
