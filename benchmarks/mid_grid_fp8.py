@@ -28,7 +28,7 @@ def t(fn, it=20):
     return best
 
 
-for causal in ((False,) if os.environ.get("MID_GRID_NONCAUSAL") else (False, True)):
+for causal in ((False,) if os.environ.get("MID_GRID_NONCAUSAL") else (True,) if os.environ.get("MID_GRID_CAUSAL") else (False, True)):
     for N in (512, 1024, 2048, 4096, 8192):
         for BH in (8, 16, 24, 32, 48, 64, 128):
             wg256 = BH * ((N + 255) // 256)
@@ -36,7 +36,7 @@ for causal in ((False,) if os.environ.get("MID_GRID_NONCAUSAL") else (False, Tru
                 continue
             Q, K, V = ((torch.randn(1, BH, N, 128, device=dev) * float(os.environ.get("MID_GRID_SPREAD", "1.0"))).to(torch.float8_e4m3fn) for _ in range(3))
             r = {"causal": causal, "N": N, "BH": BH, "wg256": wg256}
-            cands = ("mfma8x", "mfma8x_w4") + (() if causal or N % 256 else ("a8",))     # (mfma8u: experiments library only)
+            cands = ("mfma8x", "mfma8x_w4") + (() if N % 256 else ("a8",))     # (mfma8u: experiments library only)
             for v in ("auto",) + cands:
                 r[v] = round(t(lambda: flash_attention_forward(Q, K, V, dev, causal=causal, variant=v)), 1)
             r["best"] = min(cands, key=lambda k: r[k])

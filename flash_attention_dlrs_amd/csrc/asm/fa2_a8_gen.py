@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generator of the gfx950 assembly kernels `fa2_fwd_a8_<e4m3|e5m2>_n` -- FA-2 forward, d = 128, OCP fp8 (BASELINE.json
+"""Generator of the gfx950 assembly kernels `fa2_fwd_a8_<e4m3|e5m2>_<c|n>` -- FA-2 forward, d = 128, OCP fp8 (BASELINE.json
 configs[4]): the a64 structure (fa2_a64_gen.py: 4 waves x 64 query rows, one wave per SIMD with all 512 registers, persistent
 grid, continuous tile stream, LDS-DMA staging, modulo-scheduled softmax) on the double-rate fp8 matrix path,
 v_mfma_f32_32x32x64_f8f6f4 -- QK^T on the plain form, P.V on the BLOCK-SCALED one (Gen.scaled): the running maximum is an integer,
@@ -21,7 +21,9 @@ as fa2_mfma8x.hip, whose layouts (validated on the device) this kernel takes ove
 A 64-key step is 8 + 8 MFMAs of 64 cycles and two of 32: the MFMA lists keep a64's 32 + 40 SLOTS with a real MFMA in every fourth
 -- emit_phase gives each MFMA the fillers of the slots it stands for, in order -- so the time line, the seam and the job stream
 are a64's.  Per step a wave issues ~1 350 cycles of softmax against 1 090 of MFMA: the kernel is VALU-issue bound.
-Non-causal, N a multiple of 256 (the other fp8 shapes stay on fa2_mfma8x.hip).
+N a multiple of 256 (the other fp8 shapes stay on fa2_mfma8x.hip).  Causal: fa2_a64_gen.py's split row map, seam bodies and lazy
+masking; the packed-P masks are byte masks (four keys per register), and the firing path of a lazily masked tile leaves again when
+the exact maximum does not pass the threshold (the oracle's decision).
 """
 from __future__ import annotations
 

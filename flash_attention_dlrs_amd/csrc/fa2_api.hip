@@ -147,8 +147,9 @@ int pick_variant(const Fa2Problem &p) {
         const long long jobs = (long long)(p.causal ? (nq256 + 1) / 2 : nq256) * p.B * p.H;
         const double x = (double)jobs / (double)cus;
         const bool even = x <= 1.0 ? x >= 0.6 : (double)((jobs + cus - 1) / cus) / x <= 1.2;
-        // the generated kernel (non-causal, N a multiple of 256): best or equal on every even grid from 192 jobs on, +5 .. +9 %
-        // from 512 jobs on; at 1.5 jobs per CU (384) its whole-job steps lose 10 % to the 4-wave kernel like the 8-wave one's
+        // the generated kernel (N a multiple of 256): best or equal on every even grid from 192 jobs on, +5 .. +9 % from 512 jobs on
+        // (causal: +8 .. +19 %, profiles/r03/mid_grid_fp8_a8_causal.jsonl, a8_causal_vs_mfma8x.jsonl); at 1.5 jobs per CU (384) its
+        // whole-job steps lose 10 % to the 4-wave kernel like the 8-wave one's
         if (fa2_a8_supports(p) && wg256 >= T(192) && even) return FA2_VARIANT_A8;
         return wg256 >= T(160) && even ? FA2_VARIANT_MFMA8X : FA2_VARIANT_MFMA8X_W4;
     }

@@ -410,7 +410,7 @@ def _fp8_close(O, L, O_ref, L_ref, V, step, same_o=0.99, same_l=0.97):
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 def test_generated_fp8_kernel_a8(oracle, dtype):
     """the generated fp8 kernel (variant a8, asm/fa2_a8_gen.py: the a64 structure on v_mfma_f32_32x32x64_f8f6f4 with P.V on its
-    block-scaled form; non-causal, N a multiple of 256): element by element against the oracle's deferred-maximum mode with an
+    block-scaled form; N a multiple of 256): element by element against the oracle's deferred-maximum mode with an
     INTEGER running maximum (ceil_m: the kernel never rescales O, the power of two rides in the MFMA's scale operand) -- the bar of
     fa2_mfma8x below; against fa2_mfma8x itself (whose maximum is not rounded up: P is rounded against another reference) within
     the same bound; several jobs per workgroup, narrow and N(0, 1) inputs (the maximum moves in most steps), (B, N, H, d)-strided
@@ -458,7 +458,8 @@ def test_generated_fp8_kernel_a8(oracle, dtype):
     assert _lib.query_tile(16384, 128, en, False, B=16, H=8)[0] == _lib.VARIANT_A8
     assert _lib.query_tile(2048, 128, en, False, B=1, H=48)[0] == _lib.VARIANT_MFMA8X_W4
     assert _lib.query_tile(2048, 128, en, False, B=1, H=16)[0] in (_lib.VARIANT_MFMA8X, _lib.VARIANT_MFMA8X_W4)
-    assert _lib.query_tile(16384, 128, en, True, B=16, H=8)[0] == _lib.VARIANT_MFMA8X
+    assert _lib.query_tile(16384, 128, en, True, B=16, H=8)[0] == _lib.VARIANT_A8
+    assert _lib.query_tile(4096, 128, en, True, B=1, H=16)[0] == _lib.VARIANT_MFMA8X_W4      # (half a unit per CU)
 
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
