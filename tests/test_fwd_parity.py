@@ -400,11 +400,11 @@ def test_golden_fp8_e5m2_on_the_gpu(oracle):
 FP8_THR = {torch.float8_e4m3fn: 8.5, torch.float8_e5m2: 15.0}    # deferral threshold of the running maximum (fa2_mfma8x.hip, fa2_a64.hip)
 
 
-def _fp8_close(O, L, O_ref, L_ref, V, step, same_o=0.99, same_l=0.97):
+def _fp8_close(O, L, O_ref, L_ref, V, step, same_o=0.99, same_l=0.97, l_abs=1e-3):
     O, L, O_ref, L_ref = O.float(), L.float().flatten(), O_ref.float(), L_ref.float().flatten()
     assert (O == O_ref).float().mean() >= same_o and (L == L_ref).float().mean() >= same_l, ((O == O_ref).float().mean(), (L == L_ref).float().mean())
     assert ((O - O_ref).abs() <= step * O_ref.abs() + 0.5 * step * V.float().abs().max()).all()
-    assert ((L - L_ref).abs() <= step * L_ref.abs() + 1e-3).all()
+    assert ((L - L_ref).abs() <= step * L_ref.abs() + l_abs).all()
 
 
 @pytest.mark.parametrize("dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
@@ -422,7 +422,7 @@ def test_generated_fp8_kernel_a8(oracle, dtype):
         Q, K, V = _rand(shape, dtype, seed=seed, spread=spread)
         O, L = hip_forward(Q, K, V, variant="a8")
         O8, L8 = hip_forward(Q, K, V, variant="mfma8x")
-        _fp8_close(O, L, O8, L8, V, step, same_o=0.5, same_l=0.9)    # (two valid roundings of P: 60-85 % of O equal between the oracle's two modes)
+        _fp8_close(O, L, O8, L8, V, step, same_o=0.5, same_l=0.9, l_abs=1.5 * step)    # (two valid roundings of P: 60-85 % of O equal between the oracle's two modes)
         if shape[0] * shape[1] <= 6:
             O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=False, G=32, B_c=64, thr=FP8_THR[dtype],
                                                    sum_rounded=True, ceil_m=True)
@@ -446,7 +446,9 @@ def test_generated_fp8_kernel_a8(oracle, dtype):
         Q, K, V = _rand(shape, dtype, seed=seed, spread=spread)      # the causal form (light jobs walk downwards from N = 512 on)
         O, L = hip_forward(Q, K, V, causal=True, variant="a8")
         O8, L8 = hip_forward(Q, K, V, causal=True, variant="mfma8x")
-        _fp8_close(O, L, O8, L8, V, step, same_o=0.5, same_l=0.9)
+        # (two roundings of P: l = sum of the rounded P is off by up to half a step relatively, log2 l by 0.72 steps absolutely --
+        # which shows where |L| is small, in a causal problem's first rows)
+        _fp8_close(O, L, O8, L8, V, step, same_o=0.5, same_l=0.9, l_abs=1.5 * step)
         if shape[0] * shape[1] <= 6:
             O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=True, G=32, B_c=64, thr=FP8_THR[dtype],
                                                    sum_rounded=True, ceil_m=True)
