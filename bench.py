@@ -37,6 +37,7 @@ CONFIGS = {  # BASELINE.json "configs"
     "ref_test": dict(B=32, H=32, N=256, d=128, dtype="f32", causal=False),  # src/test_correctness.py:9-14
     "f32_long": dict(B=2, H=16, N=4096, d=128, dtype="f32", causal=False),
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
+    "ref_bench_bf16": dict(B=8, H=16, N=4096, d=128, dtype="bf16", causal=False),
     "d64_long": dict(B=8, H=16, N=4096, d=64, dtype="fp16", causal=False),
     "d64_long_causal": dict(B=8, H=16, N=4096, d=64, dtype="bf16", causal=True),
     "d64_8k": dict(B=4, H=16, N=8192, d=64, dtype="bf16", causal=False),
