@@ -146,6 +146,7 @@ def cases():
     # beside the 64-cycle fp8 MFMA (a8): unit costs and orderings of a run of the step's fillers (4 exp, 4 fma, 2 cvt, 2 max3, 1 read)
     C8 = lambda u, k: I("v_cvt_pk_fp8_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), op_sel=(0, 0, k & 1))
     C8D = lambda u, k: I("v_cvt_pk_fp8_f32", V(r(u, 0)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), op_sel=(0, 0, k & 1))   # same destination
+    MULS = lambda u, k: I("v_mul_f32", V(r(u, k)), S(21), V(r(u, k)))      # x = c * s' (VOP2, scalar c): what is left of the fma if -m rides in the MFMA's C operand
     CS8 = lambda u, k: I("v_cvt_scalef32_pk_fp8_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)), 1.0, op_sel=(0, 0, 0, k & 1))
     CH8 = lambda u, k: I("v_cvt_scalef32_pk_fp8_f16", V(r(u, k)), V(r(u, (k + 1) % 8)), 1.0)
     CHF = lambda u, k: I("v_cvt_pk_f16_f32", V(r(u, k)), V(r(u, (k + 1) % 8)), V(r(u, (k + 2) % 8)))
@@ -155,6 +156,9 @@ def cases():
         "c4": [C8] * 4, "c8": [C8] * 8, "c12": [C8] * 12, "c8d": [C8D] * 8, "cb8": [CVT] * 8, "m8": [MX3] * 8, "m12": [MX3] * 12,
         "t4": [TR8] * 4, "t8": [TR8] * 8, "cs4": [CS8] * 4, "cs8": [CS8] * 8, "cs12": [CS8] * 12, "ch8": [CH8] * 8, "chf8": [CHF, CH8] * 4,
         "mix_il_cs": [TR8, EXP, FMA, CS8, MX3, EXP, FMA, EXP, FMA, CS8, EXP, FMA, MX3],
+        "mul8": [MULS] * 8, "mul12": [MULS] * 12, "mul16": [MULS] * 16, "em4": [EXP, MULS] * 4, "em6": [EXP, MULS] * 6, "em8": [EXP, MULS] * 8,
+        "mix_il_mul": [TR8, EXP, MULS, C8, MX3, EXP, MULS, EXP, MULS, C8, EXP, MULS, MX3],
+        "mix_il_mul_x2": [TR8, EXP, MULS, C8, MX3, EXP, MULS, EXP, MULS, C8, EXP, MULS, MX3] * 2,
         "mix_il": [TR8, EXP, FMA, C8, MX3, EXP, FMA, EXP, FMA, C8, EXP, FMA, MX3],
         "mix_grp": [TR8, EXP, EXP, EXP, EXP, FMA, FMA, FMA, FMA, C8, C8, MX3, MX3],
         "mix_il_nocv": [TR8, EXP, FMA, MX3, EXP, FMA, EXP, FMA, EXP, FMA, MX3],
