@@ -442,7 +442,8 @@ def test_generated_fp8_kernel_a8(oracle, dtype):
     x = torch.zeros(1, 2, 320, 128).to(dtype)
     with pytest.raises(TypeError):
         hip_forward(x, x, x, variant="a8")                 # N not a multiple of 256
-    for shape, seed, spread in (((1, 2, 256, 128), 15, 0.5), ((2, 3, 768, 128), 16, 0.7), ((1, 24, 1024, 128), 17, 1.0), ((1, 4, 2048, 128), 18, 1.0)):
+    for shape, seed, spread in (((1, 2, 256, 128), 15, 0.5), ((2, 3, 768, 128), 16, 0.7), ((1, 24, 1024, 128), 17, 1.0), ((1, 4, 2048, 128), 18, 1.0),
+                                ((1, 8, 4096, 128), 19, 1.0), ((1, 8, 4352, 128), 20, 0.7)):      # (16 / 17 query blocks: the last with, the first without the downward walk)
         Q, K, V = _rand(shape, dtype, seed=seed, spread=spread)      # the causal form (light jobs walk downwards from N = 512 on)
         O, L = hip_forward(Q, K, V, causal=True, variant="a8")
         O8, L8 = hip_forward(Q, K, V, causal=True, variant="mfma8x")
