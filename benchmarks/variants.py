@@ -34,7 +34,7 @@ def main():
         env = envs[f"{cfg}:{var}"]
         for k, val in env.items():
             os.environ[k] = val
-        flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var.split(":")[0])
+        flash_attention_forward(Q, K, V, dev, causal=CONFIGS[cfg]["causal"], variant=var.split(":")[0], scale=float(env.get("SCALE", 1.0)))
         for k in env:
             os.environ.pop(k, None)
     data = {}

@@ -91,7 +91,11 @@ int pick_variant(const Fa2Problem &p) {
             // +4.4 %, N = 2048 +1.3 %; causal N = 8192 +2.0 %, N = 4096 -1.0 %, N = 2048 -3.5 % (short jobs: the seam and the
             // epilogue grow with the cycles, the clock gain is smaller there); f16 (rescales every few tiles) -2.5 %.
             // It has no ragged form yet.
-            if (p.dtype == FA2_DTYPE_BF16 && (p.N & 255) == 0 && (p.causal ? p.N >= 8192 : p.N >= 4096)) return FA2_VARIANT_A16;
+            // f16 at the reference's scale of 1 rescales every few tiles (P must stay below 65 504), which the 16x16 form pays for
+            // twice (-3 %); at the usual softmax scales the maximum rarely moves: scale 0.5 / 0.25 / 1 / sqrt(128) on the reference
+            // bench's shape: +3.0 / +5.4 / +3.6 % (scripts/gpu_f16_scale.sh, profiles/r03/f16_scale_a16_vs_a64.jsonl)
+            const bool a16_dtype = p.dtype == FA2_DTYPE_BF16 || (p.dtype == FA2_DTYPE_F16 && p.scale <= 0.5f);
+            if (a16_dtype && (p.N & 255) == 0 && (p.causal ? p.N >= 8192 : p.N >= 4096)) return FA2_VARIANT_A16;
             return FA2_VARIANT_A64;
         }
         // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and

@@ -107,7 +107,8 @@ int fa2_fwd_variant(const void *Q, const void *K, const void *V, void *O, void *
 int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int32_t out4[4]);
 
 /* The table's choice depends on the grid size (B * H tiles must fill 256 CUs): fa2_query_tile answers for a large grid
- * (B = 64, H = 8), fa2_query_tile_ex for the given B and H -- the variant fa2_fwd() runs for that contiguous problem. */
+ * (B = 64, H = 8), fa2_query_tile_ex for the given B and H -- the variant fa2_fwd() runs for that contiguous problem at
+ * scale = 1 (the reference's; f16 at scale <= 0.5 may run A16 where this reports A64). */
 int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal,
                       int32_t out4[4]);
 
