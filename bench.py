@@ -38,6 +38,8 @@ CONFIGS = {  # BASELINE.json "configs"
     "f32_long": dict(B=2, H=16, N=4096, d=128, dtype="f32", causal=False),
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
     "ref_bench_bf16": dict(B=8, H=16, N=4096, d=128, dtype="bf16", causal=False),
+    "c3_fp16": dict(B=4, H=32, N=4096, d=128, dtype="fp16", causal=True),
+    "causal_2k_fp16": dict(B=8, H=32, N=2048, d=128, dtype="fp16", causal=True),
     "d64_long": dict(B=8, H=16, N=4096, d=64, dtype="fp16", causal=False),
     "d64_long_causal": dict(B=8, H=16, N=4096, d=64, dtype="bf16", causal=True),
     "d64_8k": dict(B=4, H=16, N=8192, d=64, dtype="bf16", causal=False),
