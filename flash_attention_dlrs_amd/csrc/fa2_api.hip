@@ -95,7 +95,11 @@ int pick_variant(const Fa2Problem &p) {
             // twice (-3 %); at the usual softmax scales the maximum rarely moves: scale 0.5 / 0.25 / 1 / sqrt(128) on the reference
             // bench's shape: +3.0 / +5.4 / +3.6 % (scripts/gpu_f16_scale.sh, profiles/r03/f16_scale_a16_vs_a64.jsonl)
             const bool a16_dtype = p.dtype == FA2_DTYPE_BF16 || (p.dtype == FA2_DTYPE_F16 && p.scale <= 0.5f);
-            if (a16_dtype && (p.N & 255) == 0 && (p.causal ? p.N >= 8192 : p.N >= 4096)) return FA2_VARIANT_A16;
+            // ... and only where the chip is full enough to sit on its power limit: on half-filled grids (128 jobs, or 128 causal
+            // units: 2.4 GHz whatever the shape) the extra cycles cost 15 % (profiles/r03/mid_grid_final.jsonl: N = 4096 B*H = 8 78.9 vs
+            // 68.3 us, causal N = 8192 B*H = 8 158.2 vs 137.8); from 192 jobs on it leads
+            const long long units16 = p.causal ? (wg256 + 1) / 2 : wg256;
+            if (a16_dtype && (p.N & 255) == 0 && (p.causal ? p.N >= 8192 : p.N >= 4096) && units16 >= T(192)) return FA2_VARIANT_A16;
             return FA2_VARIANT_A64;
         }
         // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and
@@ -105,7 +109,10 @@ int pick_variant(const Fa2Problem &p) {
         // B1 H8 N4096 d128 causal 112.8 -> 79.3.  At 192 units and above the plain kernels are as fast or faster.
         const long long wg128 = (long long)((p.N + 127) / 128) * p.B * p.H;
         if ((p.causal ? wg128 / 2 : wg128) <= T(128)) {
-            if (wg128 > T(128)) return FA2_VARIANT_MFMA16K;  // causal, 129..256 tiles: 128-row tiles, two key groups
+            // causal, 129..256 tiles: 128-row tiles, two key groups -- except d = 64 at two 64-row workgroups per CU and long rows,
+            // where the (2, 4) shape leads (mid_grid_final.jsonl: N = 4096 B*H = 8 39.6 vs 51.2 us, N = 2048 B*H = 16 25.0 vs 29.1; at
+            // 1.5 per CU or N = 1024 it loses)
+            if (wg128 > T(128)) return p.d == 64 && p.N >= 2048 && wg128 > T(224) ? FA2_VARIANT_MFMA16K_R2K4 : FA2_VARIANT_MFMA16K;
             if (p.d == 64 && p.N >= 512) return FA2_VARIANT_MFMA16K_R2K4;
             return FA2_VARIANT_MFMA16K_R2K2;
         }
