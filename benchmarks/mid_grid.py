@@ -32,16 +32,19 @@ def t(fn, it=30):
 
 
 ONLY_D = [int(x) for x in os.environ.get("MID_GRID_D", "128,64").split(",")]
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("MID_GRID_DTYPE", "bf16")]      # (f16 rescales every few tiles at scale 1)
+BHS = [int(x) for x in os.environ.get("MID_GRID_BH", "8,12,16,24,32,48,64").split(",")]
+NS = [int(x) for x in os.environ.get("MID_GRID_N", "1024,2048,4096,8192").split(",")]
 for d in ONLY_D:
     for causal in (False, True):
-        for N in (1024, 2048, 4096, 8192):
-            for BH in (8, 12, 16, 24, 32, 48, 64):
+        for N in NS:
+            for BH in BHS:
                 wg256 = BH * ((N + 255) // 256)
-                if wg256 < 64 or wg256 > 1100:
+                if wg256 < 32 or wg256 > 1100:
                     continue
-                Q, K, V = (torch.randn(1, BH, N, d, device=dev).to(torch.bfloat16) for _ in range(3))
+                Q, K, V = (torch.randn(1, BH, N, d, device=dev).to(DT) for _ in range(3))
                 r = {"d": d, "causal": causal, "N": N, "BH": BH, "wg256": wg256}
-                cands = ("mfma16d_w4", "mfma16h", "mfma16k") + (("a64",) if d == 128 and N % 256 == 0 else ()) + \
+                cands = ("mfma16d_w4", "mfma16h", "mfma16k", "mfma16k_r2k2") + (("a64",) if d == 128 and N % 256 == 0 else ()) + \
                     (("a64d", "mfma16k_r2k4") if d == 64 and N % 256 == 0 else ())
                 for v in ("auto",) + cands:
                     r[v] = round(t(lambda: flash_attention_forward(Q, K, V, dev, causal=causal, variant=v)), 1)

@@ -84,7 +84,14 @@ int pick_variant(const Fa2Problem &p) {
         // of 256 rows on A64D is the best of the six kernels or within 4 % of it; below, the key-split and 128-row kernels keep more
         // CUs busy (64 jobs: 13.1 us for MFMA16K_R2K4 against 17.0)
         if (fa2_a64d_supports(p) && wg256 >= T(p.causal ? 192 : 160)) return FA2_VARIANT_A64D;
-        if (fa2_a64_supports(p) && (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64))) {
+        // f16 at the reference's scale of 1 rescales every few tiles (P must stay below 65 504); with one wave per SIMD a rescale is
+        // ~2 000 cycles with three waves waiting, which the 8-wave kernels hide.  On a full chip A64 still leads; on half-filled
+        // grids it loses 12 .. 30 % to them (profiles/r03/mid_grid_f16.jsonl: 64 jobs 30.9 vs 21.5 us, 128 jobs 32.0 vs 27.0, causal
+        // N = 2048 128 jobs 60.1 vs 45.2), where bf16 -- which never rescales -- wins.  At softmax scales <= 0.5 f16 behaves like bf16.
+        const bool f16_hot = p.dtype == FA2_DTYPE_F16 && p.scale > 0.5f;
+        const bool a64_grid = f16_hot ? wg256 >= T(256)
+                                      : (p.causal ? (wg256 >= T(192) || (wg256 >= T(96) && p.N >= 2048)) : wg256 >= T(64));
+        if (fa2_a64_supports(p) && a64_grid) {
             // The same kernel on the other matrix shape (A16: v_mfma_f32_16x16x32, asm/fa2_a16_gen.py): 15 % more cycles per key
             // step, but the chip holds a 10-17 % higher clock under it.  Same-device A/B against A64 (benchmarks/variants.py,
             // profiles/r03/a16_vs_a64.jsonl), bf16: non-causal N = 4096 +2.4 .. +4.4 %, N = 8192 (BASELINE configs[3]'s shard)
