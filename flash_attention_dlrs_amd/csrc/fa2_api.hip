@@ -83,7 +83,10 @@ int pick_variant(const Fa2Problem &p) {
         // Grid rule from the d = 64 mid-grid sweep (benchmarks/mid_grid.py, profiles/r03/mid_grid_d64.jsonl, 48 shapes): from 192 jobs
         // of 256 rows on A64D is the best of the six kernels or within 4 % of it; below, the key-split and 128-row kernels keep more
         // CUs busy (64 jobs: 13.1 us for MFMA16K_R2K4 against 17.0)
-        if (fa2_a64d_supports(p) && wg256 >= T(p.causal ? 192 : 160)) return FA2_VARIANT_A64D;
+        // (f16 at the reference's scale of 1 -- rescales every few tiles, see A64 below -- causal: only from 384 jobs = 192 units on;
+        // at 128 units the 8-wave kernels lead by 3 .. 13 %, profiles/r03/mid_grid_f16_d64.jsonl)
+        const bool f16_hot64 = p.dtype == FA2_DTYPE_F16 && p.scale > 0.5f;
+        if (fa2_a64d_supports(p) && wg256 >= T(p.causal ? (f16_hot64 ? 384 : 192) : 160)) return FA2_VARIANT_A64D;
         // f16 at the reference's scale of 1 rescales every few tiles (P must stay below 65 504); with one wave per SIMD a rescale is
         // ~2 000 cycles with three waves waiting, which the 8-wave kernels hide.  On a full chip A64 still leads; on half-filled
         // grids it loses 12 .. 30 % to them (profiles/r03/mid_grid_f16.jsonl: 64 jobs 30.9 vs 21.5 us, 128 jobs 32.0 vs 27.0, causal
