@@ -1411,14 +1411,19 @@ class Gen:
         e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH, S_KSN), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH, S_VSN))
         e(I("s_mov_b32", S_KDMA, S_KW), I("s_mov_b32", S_VDMA, S_VW))
         e(self.stamp(0))
-        for j in range(self.dk - 1):
-            e(self.dma_tile("k", j % self.R))
-            if j < self.dv - 1:
-                e(self.dma_tile("v", j % self.R))
+        # (the first QK^T needs the Q rows and K(0) only: they go first, and the wait in front of the first barrier leaves the other
+        # tiles in flight -- all 256 workgroups start at once and the burst is bandwidth-bound, ~7 us for everything)
         qs_setup, qs_pieces = self.q_stage(S_B, S_HH, S_QI)
         e(qs_setup, [pc + [I("s_nop", 0), ld] for pc, ld in qs_pieces])
+        late = []
+        for j in range(self.dk - 1):
+            (e if j == 0 and "prologue_old" not in self.abl else late.append)(self.dma_tile("k", j % self.R))
+            if j < self.dv - 1:
+                late.append(self.dma_tile("v", j % self.R))
+        e(late)
+        n_late = sum(1 for t in late for x in t if x.op.startswith("buffer_load")) if "prologue_old" not in self.abl else 0   # (A/B variant: wait for everything)
         e([I("v_accvgpr_write_b32", A(k), 0) for k in range(128)])   # O^T := 0
-        e(waitcnt(vmcnt=0), I("s_barrier"))
+        e(waitcnt(vmcnt=n_late), I("s_barrier"))
         e(self.stamp(1))
         e(self.q_reads(), self.k_reads(0))
         # step -1 (buffers as t4 = 3): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(2), K(3)
@@ -1604,7 +1609,7 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
 # lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
 # issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)),
+VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)), "prologue_old": dict(abl=("prologue_old",)),
             "norowsum": dict(abl=("no_rowsum",))}     # (norowsum: timing-only bound of what the row-sum MFMAs cost; outputs are wrong)
 
 

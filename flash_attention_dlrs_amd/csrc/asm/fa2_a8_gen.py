@@ -1460,14 +1460,19 @@ class Gen:
         e(self.make_desc(S_KRS, S_K, S_KSB, S_KSH, S_B, S_HH, S_KSN), self.make_desc(S_VRS, S_V, S_VSB, S_VSH, S_B, S_HH, S_VSN))
         e(I("s_mov_b32", S_KDMA, S_KW), I("s_mov_b32", S_VDMA, S_VW))
         e(self.stamp(0))
-        for j in range(self.dk - 1):
-            e(self.dma_tile("k", j % self.R))
-            if j < self.dv - 1:
-                e(self.dma_tile("v", j % self.R))
+        # (the first QK^T needs the Q rows and K(0) only: they go first, and the wait in front of the first barrier leaves the other
+        # tiles in flight -- all 256 workgroups start at once and the burst is bandwidth-bound, ~7 us for everything)
         qs_setup, qs_pieces = self.q_stage(S_B, S_HH, S_QI)
         e(qs_setup, [pc + [I("s_nop", 0), ld] for pc, ld in qs_pieces])
+        late = []
+        for j in range(self.dk - 1):
+            (e if j == 0 else late.append)(self.dma_tile("k", j % self.R))
+            if j < self.dv - 1:
+                late.append(self.dma_tile("v", j % self.R))
+        e(late)
+        n_late = sum(1 for t in late for x in t if x.op.startswith("buffer_load"))
         e([I("v_accvgpr_write_b32", A(k), 0) for k in range(128)])   # O^T := 0
-        e(waitcnt(vmcnt=0), I("s_barrier"))
+        e(waitcnt(vmcnt=n_late), I("s_barrier"))
         e(self.stamp(1))
         e(self.q_reads(), self.k_reads(0))
         # step -1 (buffers as t4 = 3): A = QK^T(0) only; B = start(0) as init, K(1) reads, DMA V(2), K(3)
