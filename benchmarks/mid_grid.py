@@ -44,7 +44,7 @@ for d in ONLY_D:
                     continue
                 Q, K, V = (torch.randn(1, BH, N, d, device=dev).to(DT) for _ in range(3))
                 r = {"d": d, "causal": causal, "N": N, "BH": BH, "wg256": wg256}
-                cands = ("mfma16d_w4", "mfma16h", "mfma16k", "mfma16k_r2k2") + (("a64",) if d == 128 and N % 256 == 0 else ()) + \
+                cands = ("mfma16d_w4", "mfma16h", "mfma16k", "mfma16k_r2k2") + (("a64",) if d == 128 and N >= 256 else ()) + (("a16",) if d == 128 and N % 256 == 0 and N >= 2048 else ()) + \
                     (("a64d", "mfma16k_r2k4") if d == 64 and N % 256 == 0 else ())
                 for v in ("auto",) + cands:
                     r[v] = round(t(lambda: flash_attention_forward(Q, K, V, dev, causal=causal, variant=v)), 1)
