@@ -359,11 +359,20 @@ def main():
     # the median / minimum run in a second, untimed pass of the same K steps.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
+    # (a blocking synchronize hands control back tens of microseconds after the GPU has gone idle, and an idle GPU takes as long
+    # again to pick up the next packet: one more launch, a spin on its event, and the timed steps follow within microseconds)
+    step()
+    evw = torch.cuda.Event()
+    evw.record()
+    while not evw.query():
+        pass
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
         step()
     ev1.record()
+    while not ev1.query():      # spin on the closing event: a blocking synchronize wakes the host tens of microseconds after the last
+        pass                    # kernel has ended -- 0.3-0.5 % of a 20-step bracket of 0.44-ms kernels; the synchronize below then returns at once
     sync_all()
     el = time.perf_counter() - t0
     if grouped:
