@@ -1319,10 +1319,11 @@ class Gen:
         def row_stores(qb, off=S_T[0], stride=S_T[1], restride=False):
             """[[instructions of one row store]] of query block qb (its rows are back in `rows`).  restride: the 4-row stride is
             formed again in front of every store (scalar code that uses `stride` runs between the stores)"""
-            pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, off)
+            omods = dict(nt=1) if "o_nt" in self.abl else dict(sc1=1) if "o_sc1" in self.abl else {}    # (A/B: streaming O stores)
+            pre, st = self.buf_op("buffer_store_dwordx4", rows[0], V(V_EO), S_SQ, off, **omods)
             out = [[I("s_mul_i32", off, S_QROW[qb], S_OSN), I("s_lshl_b32", stride, S_OSN, 2)] + pre + [st]]
             for k in range(1, 8):
-                pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, off)
+                pre, st = self.buf_op("buffer_store_dwordx4", rows[k], V(V_EO), S_SQ, off, **omods)
                 out.append(([I("s_lshl_b32", stride, S_OSN, 2)] if restride else []) + [I("s_add_u32", off, off, stride)] + pre + [st])
             return out
 
@@ -1609,7 +1610,7 @@ ABLATIONS = {"novmwait": ("novmwait",), "nobarrier": ("nobarrier",),
 # lean bodies); V reads doubled up in 2 instead of 4 gaps 0.  Split row map (the default since) against the contiguous one with
 # lean bodies ("nosplit"): +0.9 / +1.1 % on two boxes, bit-identical outputs (benchmarks/a64_variant_equal.py); its DMA pieces
 # issued in the first gaps of the short steps: 0.
-VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)), "prologue_old": dict(abl=("prologue_old",)),
+VARIANTS = {"base": dict(), "nosplit": dict(split=False), "fullmax": dict(abl=("full_max",)), "prologue_old": dict(abl=("prologue_old",)), "o_nt": dict(abl=("o_nt",)), "o_sc1": dict(abl=("o_sc1",)),
             "norowsum": dict(abl=("no_rowsum",))}     # (norowsum: timing-only bound of what the row-sum MFMAs cost; outputs are wrong)
 
 
