@@ -49,7 +49,7 @@ if os.path.basename(LIB_PATH) in ("libfa2_hip_exp.so", "libfa2_hip_abl.so"):
     VARIANTS.update(EXPERIMENTAL_VARIANTS)
 
 # Every symbol include/fa2_fwd.h declares (tests/test_abi.py checks the export list against the header).
-SYMBOLS = ("fa2_fwd", "fa2_fwd_variant", "fa2_query_tile", "fa2_query_tile_ex", "fa2_version", "fa2_last_error")
+SYMBOLS = ("fa2_fwd", "fa2_fwd_variant", "fa2_query_tile", "fa2_query_tile_ex", "fa2_query_tile_scaled", "fa2_version", "fa2_last_error")
 # ... and include/fa2_bwd.h
 BWD_SYMBOLS = ("fa2_bwd", "fa2_bwd_variant")
 BWD_VARIANTS = {"auto": 0, "generic": 1, "mfma16": 2, "mfma32": 3}
@@ -85,6 +85,8 @@ def lib():
         l.fa2_query_tile.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
         l.fa2_query_tile_ex.restype = ctypes.c_int
         l.fa2_query_tile_ex.argtypes = [ctypes.c_int32] * 6 + [ctypes.POINTER(ctypes.c_int32)]
+        l.fa2_query_tile_scaled.restype = ctypes.c_int
+        l.fa2_query_tile_scaled.argtypes = [ctypes.c_int32] * 6 + [ctypes.c_float, ctypes.POINTER(ctypes.c_int32)]
         bwd = [vp] * 10 + [i64p] * 9 + [ctypes.c_int32] * 6 + [ctypes.c_float, vp]
         l.fa2_bwd.restype = ctypes.c_int
         l.fa2_bwd.argtypes = bwd
@@ -102,11 +104,14 @@ def version():
     return lib().fa2_version().decode()
 
 
-def query_tile(N, d, dtype_enum, causal=False, B=None, H=None):
+def query_tile(N, d, dtype_enum, causal=False, B=None, H=None, scale=None):
     """(variant, B_r, B_c, waves) the static table picks; the choice depends on the grid size, so pass B and H for the
-    variant an actual (B, H, N, d) launch takes (default: a large grid, B = 64, H = 8)"""
+    variant an actual (B, H, N, d) launch takes (default: a large grid, B = 64, H = 8) -- and, for f16, on the softmax scale
+    (default 1, the reference's)"""
     out = (ctypes.c_int32 * 4)()
-    if B is None or H is None:
+    if scale is not None:
+        rc = lib().fa2_query_tile_scaled(64 if B is None else B, 8 if H is None else H, N, d, dtype_enum, int(bool(causal)), float(scale), out)
+    elif B is None or H is None:
         rc = lib().fa2_query_tile(N, d, dtype_enum, int(bool(causal)), out)
     else:
         rc = lib().fa2_query_tile_ex(B, H, N, d, dtype_enum, int(bool(causal)), out)

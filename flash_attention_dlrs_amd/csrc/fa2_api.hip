@@ -329,6 +329,11 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
 }
 
 int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int32_t out4[4]) {
+    return fa2_query_tile_scaled(B, H, N, d, dtype_enum, causal, 1.0f, out4);
+}
+
+int fa2_query_tile_scaled(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, float scale,
+                          int32_t out4[4]) {
     if (!out4) {
         fa2_set_error("out4 is null");
         return FA2_ERR_BAD_ARG;
@@ -338,7 +343,7 @@ int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_
     memset(&p, 0, sizeof(p));
     p.Q = p.K = p.V = (const void *)0x1000;
     p.O = p.L = (void *)0x1000;
-    p.B = B; p.H = H; p.N = N; p.d = d; p.dtype = dtype_enum; p.causal = causal ? 1 : 0; p.scale = 1.0f;
+    p.B = B; p.H = H; p.N = N; p.d = d; p.dtype = dtype_enum; p.causal = causal ? 1 : 0; p.scale = scale;
     const int64_t s[4] = {(int64_t)H * N * d, (int64_t)N * d, d, 1};
     for (int k = 0; k < 4; ++k) p.qs[k] = p.ks[k] = p.vs[k] = p.os[k] = s[k];
     p.ls[0] = (int64_t)H * N; p.ls[1] = N;

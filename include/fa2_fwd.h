@@ -108,9 +108,14 @@ int fa2_query_tile(int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, int
 
 /* The table's choice depends on the grid size (B * H tiles must fill 256 CUs): fa2_query_tile answers for a large grid
  * (B = 64, H = 8), fa2_query_tile_ex for the given B and H -- the variant fa2_fwd() runs for that contiguous problem at
- * scale = 1 (the reference's; f16 at scale <= 0.5 may run A16 where this reports A64). */
+ * scale = 1 (the reference's). */
 int fa2_query_tile_ex(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal,
                       int32_t out4[4]);
+
+/* ... and for a given softmax scale: f16 rescales its accumulators every few key tiles at the reference's scale of 1 (P must stay
+ * below 65 504) and hardly ever at the usual 1 / sqrt(d), which moves two of the table's thresholds (fa2_api.hip). */
+int fa2_query_tile_scaled(int32_t B, int32_t H, int32_t N, int32_t d, int32_t dtype_enum, int32_t causal, float scale,
+                          int32_t out4[4]);
 
 /* "fa2-hip <semver> gfx950". */
 const char *fa2_version(void);

@@ -144,6 +144,15 @@ def test_static_tile_table():
     assert q(128, 37, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_GENERIC
     with pytest.raises(TypeError):
         q(128, 513, _lib.FA2_DTYPE_F32)
+    # f16 depends on the softmax scale (fa2_query_tile_scaled): at the reference's scale of 1 it rescales every few key tiles, which a
+    # one-wave-per-SIMD kernel pays for on half-filled grids and the 16x16x32 form pays twice; at the usual scales it follows bf16
+    F16, BF16 = _lib.FA2_DTYPE_F16, _lib.FA2_DTYPE_BF16
+    assert q(1024, 128, F16, False, B=1, H=16)[0] == _lib.VARIANT_MFMA16K_R2K2 and q(1024, 128, BF16, False, B=1, H=16)[0] == _lib.VARIANT_A64
+    assert q(1024, 128, F16, False, B=1, H=16, scale=0.25)[0] == _lib.VARIANT_A64
+    assert q(4096, 128, F16, False, B=1, H=64)[0] == _lib.VARIANT_A64 and q(4096, 128, F16, False, B=1, H=64, scale=128 ** -0.5)[0] == _lib.VARIANT_A16
+    assert q(4096, 128, BF16, False, B=1, H=8)[0] == _lib.VARIANT_A64          # (a16 only from 192 jobs per 256 CUs on)
+    assert q(4096, 64, F16, True, B=1, H=16)[0] != _lib.VARIANT_A64D and q(4096, 64, F16, True, B=1, H=16, scale=0.25)[0] == _lib.VARIANT_A64D
+    assert q(4096, 64, BF16, True, B=1, H=8)[0] == _lib.VARIANT_MFMA16K_R2K4     # (two 64-row workgroups per CU)
 
 
 def test_host_side_and_oracle_under_address_sanitizer():
