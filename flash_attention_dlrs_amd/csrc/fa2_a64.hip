@@ -239,6 +239,14 @@ int launch(const Fa2Problem &p, int shape16) {
     {
         const char *pv = getenv("FA2_A64_PAIRS");     // A/B runs: FA2_A64_PAIRS=0: every job walks upwards
         if (pv && *pv == '0') down = false;
+        const char *gv = getenv("FA2_A64_GROUP");     // A/B runs: heads per XCD group of the causal unit order
+        if (gv && *gv && p.causal && (a.nbh & 7) == 0) {
+            int g = atoi(gv);
+            const int per_xcd = a.nbh / 8;
+            g = g < 1 ? 1 : (g > per_xcd ? per_xcd : g);
+            while (per_xcd % g) --g;
+            a.group = g;
+        }
     }
 #endif
     // persistent grid: one workgroup per CU, a multiple of 8 when there is more work than CUs (XCD affinity of the units)
