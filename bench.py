@@ -346,7 +346,7 @@ def main():
     # 751 TFLOP/s with 5 warm-up steps vs 831 with 50 on the same device).  Spin ~0.25 s of the same kernel
     # before the W untimed warm-up steps so that short (K, W) choices measure the steady state too.
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.25:
+    while time.perf_counter() - t_spin < float(os.environ.get("FA2_BENCH_SPIN", "0.25")):
         for _ in range(20):
             step()
         torch.cuda.synchronize(dev)
