@@ -38,6 +38,9 @@ CONFIGS = {  # BASELINE.json "configs"
     "f32_long": dict(B=2, H=16, N=4096, d=128, dtype="f32", causal=False),
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
     "ref_bench_bf16": dict(B=8, H=16, N=4096, d=128, dtype="bf16", causal=False),
+    "ragged_8k": dict(B=8, H=8, N=8100, d=128, dtype="bf16", causal=False),
+    "ragged_4k": dict(B=4, H=32, N=4000, d=128, dtype="bf16", causal=False),
+    "ragged_8k_causal": dict(B=8, H=8, N=8100, d=128, dtype="bf16", causal=True),
     "c3_fp16": dict(B=4, H=32, N=4096, d=128, dtype="fp16", causal=True),
     "causal_2k_fp16": dict(B=8, H=32, N=2048, d=128, dtype="fp16", causal=True),
     "d64_long": dict(B=8, H=16, N=4096, d=64, dtype="fp16", causal=False),

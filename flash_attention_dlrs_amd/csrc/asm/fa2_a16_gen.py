@@ -905,15 +905,17 @@ class Gen:
             return []          # at least one key of tile 0 is real
         assert cond is None
         sel = [I("s_cmp_gt_i32", S_KT0, 64 * j), I("s_cselect_b64", VCC, -1, 0)]     # VCC: the tile holds a real key
-        if kind == "ms":
-            qb = payload
-            return sel + [I("v_mov_b32", V(V_MSV[qb]), V(V_MC[qb])), I("v_cndmask_b32", V(V_MC[qb]), -NINF, V(V_MC[qb]), VCC)]
-        return sel + [I("v_cndmask_b32", V(V_MC[qb]), V(V_MSV[qb]), V(V_MC[qb]), VCC) for qb in range(2)]
+        if kind == "ms":       # (payload: the 32-row query block of the plan = the 16-row blocks 2 qh, 2 qh + 1, each with its own maximum)
+            out = list(sel)
+            for q in (2 * payload, 2 * payload + 1):
+                out += [I("v_mov_b32", V(V_MSV[q]), V(V_MC[q])), I("v_cndmask_b32", V(V_MC[q]), -NINF, V(V_MC[q]), VCC)]
+            return out
+        return sel + [I("v_cndmask_b32", V(V_MC[q]), V(V_MSV[q]), V(V_MC[q]), VCC) for q in range(4)]
 
     def mask_tail_tests(self, Y, g, j, cond):
         """in front of score group g's first row-maximum operation: if some of its 32 keys lie at or behind N (and some key of
-        the tile is real: else mask_tail deals with it), -inf into those scores, out of line.  Register r of a group <-> key
-        (r & 3) + 8 (r >> 2) + 4 h of the group's 32"""
+        the tile is real: else mask_tail deals with it), -inf into those scores, out of line.  Register r = 8 q' + 4 k' + rr of a group
+        <-> key 16 k' + 4 g_l + rr of the group's 32 (g_l = lane >> 4)"""
         kb = g & 1
         l_m, l_back = self.lab("tail"), self.lab("tail_back")
         t = V(V_T[6])
@@ -922,12 +924,12 @@ class Gen:
             blk += [I("s_cmp_eq_u32", cond[0], cond[1]), I("s_cbranch_scc0", Label(l_back))]
         if j > 0:
             blk += [I("s_cmp_gt_i32", S_KT0, 64 * j), I("s_cbranch_scc0", Label(l_back))]
-        # T = real keys of this group minus the lane half's offset: register r is kept iff T > (r & 3) + 8 (r >> 2)
+        # T = real keys of this group minus the lane group's offset 4 g_l: register r is kept iff T > (r & 3) + 16 ((r >> 2) & 1)
         # (S_X2, the job decode's scratch: the S_T temporaries may be in the middle of a descriptor computation spread over gaps)
-        blk += [I("s_sub_i32", S_X2, S_KT0, 64 * j + 32 * kb), I("v_lshrrev_b32", t, 5, V(V_LANE)), I("v_lshlrev_b32", t, 2, t),
+        blk += [I("s_sub_i32", S_X2, S_KT0, 64 * j + 32 * kb), I("v_lshrrev_b32", t, 4, V(V_LANE)), I("v_lshlrev_b32", t, 2, t),
                 I("v_sub_u32", t, S_X2, t)]
         for r in range(16):
-            blk += [I("v_cmp_gt_i32", VCC, t, (r & 3) + 8 * (r >> 2)), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
+            blk += [I("v_cmp_gt_i32", VCC, t, (r & 3) + 16 * ((r >> 2) & 1)), I("v_cndmask_b32", V(Y + 16 * g + r), NINF, V(Y + 16 * g + r), VCC)]
         self.ool.append(blk + [I("s_branch", Label(l_back))])
         # in line: one compare and an untaken branch while all 32 keys of the group are real
         return [I("s_cmp_lt_i32", S_KT0, 64 * j + 32 * kb + 32), I("s_cbranch_scc1", Label(l_m)), label(l_back)]
@@ -1549,7 +1551,7 @@ def product_gens():
     """the kernels of this generator that ship in libfa2_hip.so's code object (built by fa2_a64_gen.main)"""
     out = []
     for dtype in ("bf16", "f16"):
-        for causal, ragged in ((False, False), (True, False)):
+        for causal, ragged in ((False, False), (True, False), (False, True), (True, True)):
             g = Gen(dtype, causal, ragged=ragged)
             g.build()
             out.append(g)

@@ -100,7 +100,6 @@ int pick_variant(const Fa2Problem &p) {
             // profiles/r03/a16_vs_a64.jsonl), bf16: non-causal N = 4096 +2.4 .. +4.4 %, N = 8192 (BASELINE configs[3]'s shard)
             // +4.4 %, N = 2048 +1.3 %; causal N = 8192 +2.0 %, N = 4096 -1.0 %, N = 2048 -3.5 % (short jobs: the seam and the
             // epilogue grow with the cycles, the clock gain is smaller there); f16 (rescales every few tiles) -2.5 %.
-            // It has no ragged form yet.
             // f16 at the reference's scale of 1 rescales every few tiles (P must stay below 65 504), which the 16x16 form pays for
             // twice (-3 %); at the usual softmax scales the maximum rarely moves: scale 0.5 / 0.25 / 1 / sqrt(128) on the reference
             // bench's shape: +3.0 / +5.4 / +3.6 % (scripts/gpu_f16_scale.sh, profiles/r03/f16_scale_a16_vs_a64.jsonl)
@@ -109,7 +108,7 @@ int pick_variant(const Fa2Problem &p) {
             // units: 2.4 GHz whatever the shape) the extra cycles cost 15 % (profiles/r03/mid_grid_final.jsonl: N = 4096 B*H = 8 78.9 vs
             // 68.3 us, causal N = 8192 B*H = 8 158.2 vs 137.8); from 192 jobs on it leads
             const long long units16 = p.causal ? (wg256 + 1) / 2 : wg256;
-            if (a16_dtype && (p.N & 255) == 0 && (p.causal ? p.N >= 8192 : p.N >= 4096) && units16 >= T(192)) return FA2_VARIANT_A16;
+            if (a16_dtype && (p.causal ? p.N >= 8192 : p.N >= 4096) && units16 >= T(192)) return FA2_VARIANT_A16;
             return FA2_VARIANT_A64;
         }
         // Small grids: at most 128 work units (128-row tiles, tile PAIRS when causal) leave half of the 256 CUs idle and

@@ -267,7 +267,8 @@ def test_nan_and_inf_inputs_propagate_like_the_oracle(oracle, variant):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("causal", [False, True])
-def test_ragged_N_vs_oracle(oracle, dtype, causal):
+@both
+def test_ragged_N_vs_oracle(oracle, dtype, causal, variant):
     """N above 256 that is not a multiple of 256: the "ragged" kernels (range-checked descriptors with every offset in the VGPR
     operand: rows past N load as zeros and are never stored; non-causal: the key tail of the job's last four tiles is masked --
     a partly real tile exactly, wholly unreal ones through +inf as running maximum).  Element-wise against the oracle's
@@ -278,7 +279,7 @@ def test_ragged_N_vs_oracle(oracle, dtype, causal):
         arena_o = torch.full((B, H, N + 8, 128), 768.0, dtype=dtype, device=DEV)
         arena_l = torch.full((B, H, N + 8, 1), 768.0, dtype=dtype, device=DEV)
         O, L = arena_o[:, :, :N], arena_l[:, :, :N]
-        _lib.fa2_fwd(Q.to(DEV), K.to(DEV), V.to(DEV), O, L, fa.convert_triton_dtype(dtype), causal=causal, variant=_lib.VARIANT_A64)
+        _lib.fa2_fwd(Q.to(DEV), K.to(DEV), V.to(DEV), O, L, fa.convert_triton_dtype(dtype), causal=causal, variant=_lib.VARIANTS[variant])
         torch.cuda.synchronize()
         assert (arena_o[:, :, N:].float() == 768.0).all() and (arena_l[:, :, N:].float() == 768.0).all(), N
         f = lambda t: t.float().numpy()

@@ -123,6 +123,7 @@ def test_static_tile_table():
     assert q(4096, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16         # long non-causal bf16: the same kernel on 16x16x32
     assert q(2048, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A64
     assert q(4096 + 64, 128, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64      # (N not a multiple of 256: its ragged form)
+    assert q(8192 + 64, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16     # (... and a16's on long jobs)
     assert q(200, 128, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64            # below one 256-row job
     assert q(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64D           # head size 64: the generated kernel at d = 64
     assert q(4096 + 64, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_MFMA16H   # (it has no ragged form)
