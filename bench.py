@@ -39,6 +39,8 @@ CONFIGS = {  # BASELINE.json "configs"
     "ref_bench": dict(B=8, H=16, N=4096, d=128, dtype="fp16", causal=False),  # src/bench.py:8-12 at N=4096
     "ref_bench_bf16": dict(B=8, H=16, N=4096, d=128, dtype="bf16", causal=False),
     "ragged_8k": dict(B=8, H=8, N=8100, d=128, dtype="bf16", causal=False),
+    "d64_ragged": dict(B=8, H=16, N=4000, d=64, dtype="bf16", causal=False),
+    "d64_ragged_causal": dict(B=8, H=16, N=4000, d=64, dtype="bf16", causal=True),
     "ragged_4k": dict(B=4, H=32, N=4000, d=128, dtype="bf16", causal=False),
     "ragged_8k_causal": dict(B=8, H=8, N=8100, d=128, dtype="bf16", causal=True),
     "c3_fp16": dict(B=4, H=32, N=4096, d=128, dtype="fp16", causal=True),

@@ -120,7 +120,7 @@ NSLOT = 24
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
                  caps=(5, 24), split=True):
-        assert dtype in ("bf16", "f16") and not ragged, "a64d: f16 / bf16, N a multiple of 256"
+        assert dtype in ("bf16", "f16"), "a64d: f16 / bf16"
         self.dtype = dtype
         self.causal = causal
         self.name = name or f"fa2_fwd_a64d_{dtype}_{'c' if causal else 'n'}{'r' if ragged else ''}"
@@ -260,7 +260,7 @@ class Gen:
     def make_desc(self, rs: Reg, base: Reg, sb: Reg, sh: Reg, b: Reg, hh: Reg, sn=None):
         """raw buffer descriptor of the (b, hh) slice of a tensor: base + b * sb + hh * sh.  N a multiple of 256: the range check
         is not used (soffset is unchecked anyway; every address the kernel forms lies inside the tensor).  Ragged kernels:
-        num_records = (N - 1) * sn + 256 bytes of rows (sn: the row stride register; an int: bytes per row of L) -- loads of
+        num_records = (N - 1) * sn + 128 bytes of rows (sn: the row stride register; an int: bytes per row of L) -- loads of
         rows past N come back as zeros, stores to them are dropped; those kernels keep every offset in the VGPR operand"""
         tmp = S(S_T[0].idx, 2)
         out = ([I("s_mov_b64", tmp, base)] + self.mad64(tmp, b, sb) + self.mad64(tmp, hh, sh) +
@@ -270,7 +270,7 @@ class Gen:
         assert sn is not None
         if isinstance(sn, int):
             return out + [I("s_mul_i32", rs.sub(2), S_N, sn)]
-        return out + [I("s_sub_u32", S_T[6], S_N, 1), I("s_mul_i32", S_T[6], S_T[6], sn), I("s_add_u32", rs.sub(2), S_T[6], 256)]
+        return out + [I("s_sub_u32", S_T[6], S_N, 1), I("s_mul_i32", S_T[6], S_T[6], sn), I("s_add_u32", rs.sub(2), S_T[6], 128)]      # (rows of 128 bytes here)
 
     def buf_op(self, op, data, voff: Reg, rsrc: Reg, soff, **mods):
         """a buffer operation at byte offset voff (per lane) + soff (scalar).  The scalar operand of the instruction is not
@@ -372,6 +372,10 @@ class Gen:
           I("s_lshl_b32", S_T[0], S_WAVE, 3), I("s_mul_i32", S_KW, S_T[0], S_KSN), I("s_mul_i32", S_VW, S_T[0], S_VSN),
           I("s_mov_b32", S_FLAG, 0), I("s_mov_b32", S_PASS, 0), I("s_mov_b32", S_FINAL, 0),
           I("s_mov_b32", S_JOB, S_WGID))
+        if self.ragged and not self.causal:
+            e(comment("ragged, non-causal: real keys in a job's last 256; -inf"),
+              I("s_sub_u32", S_T[0], S_NQ, 1), I("s_lshl_b32", S_T[0], S_T[0], 8), I("s_sub_u32", S_KT0, S_N, S_T[0]),
+              I("v_mov_b32", NINF, float("-inf")))
         if self.causal:
             e(comment("causal: lane constants of the diagonal mask"),
               I("v_and_b32", t0, 31, lane), I("v_lshrrev_b32", t3, 5, lane), I("v_lshlrev_b32", t3, 2, t3),
@@ -1556,7 +1560,8 @@ def product_gens():
     out = []
     for dtype in ("bf16", "f16"):
         for causal in (False, True):
-            g = Gen(dtype, causal)
-            g.build()
-            out.append(g)
+            for ragged in (False, True):
+                g = Gen(dtype, causal, ragged=ragged)
+                g.build()
+                out.append(g)
     return out

@@ -41,7 +41,7 @@ struct DevState {
     hipModule_t mod = nullptr;
     hipFunction_t fn[2][2][2][2] = {};  // [a64 / a16][bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
     hipFunction_t fn8[2][2] = {};       // a8: [e4m3 / e5m2][non-causal / causal], N % 256 == 0
-    hipFunction_t fnd[2][2] = {};       // a64d (head size 64): [bf16 / f16][non-causal / causal], N % 256 == 0
+    hipFunction_t fnd[2][2][2] = {};    // a64d (head size 64): [bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
     int cus = 0;
 };
 DevState g_dev[kMaxDev];
@@ -89,12 +89,13 @@ DevState *dev_state() {
             if (e != hipSuccess) d.fn8[t][c] = nullptr;
         }
     for (int t = 0; t < 2; ++t)
-        for (int c = 0; c < 2; ++c) {
-            char nm[64];
-            snprintf(nm, sizeof(nm), "fa2_fwd_a64d_%s_%s", t ? "f16" : "bf16", c ? "c" : "n");
-            e = hipModuleGetFunction(&d.fnd[t][c], d.mod, nm);
-            if (e != hipSuccess) d.fnd[t][c] = nullptr;
-        }
+        for (int c = 0; c < 2; ++c)
+            for (int r = 0; r < 2; ++r) {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "fa2_fwd_a64d_%s_%s%s", t ? "f16" : "bf16", c ? "c" : "n", r ? "r" : "");
+                e = hipModuleGetFunction(&d.fnd[t][c][r], d.mod, nm);
+                if (e != hipSuccess) d.fnd[t][c][r] = nullptr;
+            }
     (void)hipGetLastError();  // a failed lookup must not surface in another launcher's hipGetLastError()
     d.cus = fa2_device_cus();
     d.ready = true;
@@ -139,7 +140,7 @@ bool fa2_a8_supports(const Fa2Problem &p) {
     for (int k = 0; k < 4; ++k)
         if (ptrs[k] & 15) return false;
     if (((p.qs[0] | p.qs[1] | p.ks[0] | p.ks[1] | p.vs[0] | p.vs[1] | p.os[0] | p.os[1]) & 15) != 0) return false;
-    const int64_t nq = p.N / 256, jobs = (int64_t)p.B * p.H * nq;
+    const int64_t nq = (p.N + 255) / 256, jobs = (int64_t)p.B * p.H * nq;
     if (jobs >= (1 << 22) || p.H >= (1 << 22) || p.ls[1] < p.N) return false;
     return true;
 }
@@ -148,7 +149,7 @@ int fa2_launch_a8(const Fa2Problem &p) { return launch(p, 2); }
 // head size 64, f16 / bf16: rows of 128 bytes; N a multiple of 256 (no ragged form); otherwise the conditions of a64
 bool fa2_a64d_supports(const Fa2Problem &p) {
     if (p.dtype != FA2_DTYPE_BF16 && p.dtype != FA2_DTYPE_F16) return false;
-    if (p.d != 64 || p.N < 256 || (p.N & 255)) return false;
+    if (p.d != 64 || p.N < 256) return false;    // N a multiple of 256: the plain kernels; any other N above 256: the ragged ones
     if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
     if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
     const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
@@ -177,7 +178,7 @@ int launch(const Fa2Problem &p, int shape16) {
     const bool f8 = shape16 == 2, d64 = shape16 == 3;
     if (d64) {
         if (!fa2_a64d_supports(p)) {
-            fa2_set_error("a64d kernel: needs f16/bf16, d = 64, N a multiple of 256, unit d-stride, 16-byte aligned rows, scale > 0");
+            fa2_set_error("a64d kernel: needs f16/bf16, d = 64, N >= 256, unit d-stride, 16-byte aligned rows, scale > 0");
             return FA2_ERR_UNSUPPORTED;
         }
     } else if (f8) {
@@ -193,7 +194,7 @@ int launch(const Fa2Problem &p, int shape16) {
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
     hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0][p.causal ? 1 : 0]
-                     : d64 ? d->fnd[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0]
+                     : d64 ? d->fnd[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0]
                            : d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {
         fa2_set_error("%s kernel: this (dtype, causal, ragged N) form is not in the code object", f8 ? "a8" : d64 ? "a64d" : shape16 ? "a16" : "a64");

@@ -76,7 +76,7 @@ int pick_variant(const Fa2Problem &p) {
         // MFMA16D_W4 / MFMA16H / MFMA16K it is 4-33 % faster on every shape from those sizes up (the persistent grid also
         // takes job counts that are not a multiple of the CU count better: 1.5 jobs per CU 180 vs 213 us); on the same
         // MI355X against MFMA16H: c3 causal +15-19 %, c3 shape non-causal +15-17 %.
-        // head size 64, N a multiple of 256: the generated kernel at d = 64 (A64D, asm/fa2_a64d_gen.py) under a64's grid rule.
+        // head size 64: the generated kernel at d = 64 (A64D, asm/fa2_a64d_gen.py; N a multiple of 256 or its ragged form) under a64's grid rule.
         // Same-device A/B against the rest of this table (profiles/r03/a64d_vs_table.jsonl), bf16 / f16: B8 H16 N4096 1 013 vs 840
         // TFLOP/s (+21 %), causal 1 014 vs 827 (+23 %); N = 8192 1 092 vs 929, causal 1 060 vs 887; B16 H32 N2048 984 vs 821,
         // causal 860 vs 677 (+27 %)

@@ -341,7 +341,19 @@ def test_a64d_head_size_64(oracle, dtype, causal):
                                            thr=60.0 if dtype == torch.bfloat16 else 15.875, sum_rounded=True)
     assert (O.float() == torch.from_numpy(O_ref)).float().mean().item() >= 0.99
     assert _lib.query_tile(4096, 64, _lib.FA2_DTYPE_BF16, causal, B=8, H=16)[0] == _lib.VARIANT_A64D
-    assert _lib.query_tile(4000, 64, _lib.FA2_DTYPE_BF16, causal, B=8, H=16)[0] != _lib.VARIANT_A64D      # no ragged form
+    assert _lib.query_tile(4000, 64, _lib.FA2_DTYPE_BF16, causal, B=8, H=16)[0] == _lib.VARIANT_A64D      # (its ragged form)
+    for N in (300, 1000, 2049):     # ragged N: canaries behind the tensors, the oracle's deferred mode element by element
+        Qr, Kr, Vr = rand3((2, 3, N, 64), dtype, seed=N)
+        arena_o = torch.full((2, 3, N + 8, 64), 768.0, dtype=dtype, device=DEV)
+        arena_l = torch.full((2, 3, N + 8, 1), 768.0, dtype=dtype, device=DEV)
+        Or_, Lr_ = arena_o[:, :, :N], arena_l[:, :, :N]
+        _lib.fa2_fwd(Qr.to(DEV), Kr.to(DEV), Vr.to(DEV), Or_, Lr_, fa.convert_triton_dtype(dtype), causal=causal, variant=_lib.VARIANT_A64D)
+        torch.cuda.synchronize()
+        assert (arena_o[:, :, N:].float() == 768.0).all() and (arena_l[:, :, N:].float() == 768.0).all(), N
+        O_ref, L_ref = oracle.forward_deferred(f(Qr), f(Kr), f(Vr), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64,
+                                               thr=60.0 if dtype == torch.bfloat16 else 15.875, sum_rounded=True)
+        assert (Or_.cpu().float() == torch.from_numpy(O_ref)).float().mean().item() >= 0.99, N
+        check(Or_.cpu(), Lr_.cpu(), torch.from_numpy(O_ref), torch.from_numpy(L_ref), dtype)
 
 
 def test_first_launch_of_the_process_under_stream_capture():

@@ -126,7 +126,7 @@ def test_static_tile_table():
     assert q(8192 + 64, 128, _lib.FA2_DTYPE_BF16, False)[0] == _lib.VARIANT_A16     # (... and a16's on long jobs)
     assert q(200, 128, _lib.FA2_DTYPE_BF16, True)[0] != _lib.VARIANT_A64            # below one 256-row job
     assert q(4096, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64D           # head size 64: the generated kernel at d = 64
-    assert q(4096 + 64, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_MFMA16H   # (it has no ragged form)
+    assert q(4096 + 64, 64, _lib.FA2_DTYPE_BF16, True)[0] == _lib.VARIANT_A64D      # (its ragged form)
     assert q(1024, 64, _lib.FA2_DTYPE_F16)[0] == _lib.VARIANT_A64D
     assert q(256, 128, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32
     assert q(128, 32, _lib.FA2_DTYPE_F32)[0] == _lib.VARIANT_MFMA32   # (d < 64: the d = 64 kernel with the missing columns zero-filled)
