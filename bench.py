@@ -63,6 +63,8 @@ CONFIGS = {  # BASELINE.json "configs"
     "fp8_4k": dict(B=4, H=32, N=4096, d=128, dtype="fp8", causal=False),
     "fp8_1k": dict(B=16, H=32, N=1024, d=128, dtype="fp8", causal=False),
     "fp8_8k_causal": dict(B=8, H=8, N=8192, d=128, dtype="fp8", causal=True),
+    "fp8_ragged": dict(B=8, H=8, N=8100, d=128, dtype="fp8", causal=False),
+    "fp8_ragged_causal": dict(B=4, H=32, N=4000, d=128, dtype="fp8", causal=True),
     "fp8_2k_causal": dict(B=8, H=32, N=2048, d=128, dtype="fp8", causal=True),
 }
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "fp8": torch.float8_e4m3fn}

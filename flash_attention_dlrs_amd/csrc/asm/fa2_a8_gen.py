@@ -21,7 +21,7 @@ as fa2_mfma8x.hip, whose layouts (validated on the device) this kernel takes ove
 A 64-key step is 8 + 8 MFMAs of 64 cycles and two of 32: the MFMA lists keep a64's 32 + 40 SLOTS with a real MFMA in every fourth
 -- emit_phase gives each MFMA the fillers of the slots it stands for, in order -- so the time line, the seam and the job stream
 are a64's.  Per step a wave issues ~1 350 cycles of softmax against 1 090 of MFMA: the kernel is VALU-issue bound.
-N a multiple of 256 (the other fp8 shapes stay on fa2_mfma8x.hip).  Causal: fa2_a64_gen.py's split row map, seam bodies and lazy
+N >= 256, ragged forms for N that is not a multiple of 256 (the other fp8 shapes stay on fa2_mfma8x.hip).  Causal: fa2_a64_gen.py's split row map, seam bodies and lazy
 masking; the packed-P masks are byte masks (four keys per register), and the firing path of a lazily masked tile leaves again when
 the exact maximum does not pass the threshold (the oracle's decision).
 """
@@ -145,7 +145,7 @@ NSLOT = 24
 class Gen:
     def __init__(self, dtype="bf16", causal=False, name=None, stamps=False, abl=(), ring=(2, 3, 2), vread_double=4, ragged=False,
                  caps=(5, 24), split=True, scaled=True):
-        assert dtype in ("e4m3", "e5m2") and not ragged, "a8: OCP fp8, N a multiple of 256"
+        assert dtype in ("e4m3", "e5m2"), "a8: OCP fp8"
         assert split or not causal, "a8: the causal kernels use the split row map"
         self.dtype = dtype
         # scaled: P.V on v_mfma_scale_f32_32x32x64_f8f6f4.  fp8 P leaves 8.5 log2 units of deferral (e4m3 tops out at 448): on N(0, 1)
@@ -1652,9 +1652,10 @@ def product_gens():
     out = []
     for dtype in ("e4m3", "e5m2"):
         for causal in (False, True):
-            g = Gen(dtype, causal)
-            g.build()
-            out.append(g)
+            for ragged in (False, True):
+                g = Gen(dtype, causal, ragged=ragged)
+                g.build()
+                out.append(g)
     return out
 
 

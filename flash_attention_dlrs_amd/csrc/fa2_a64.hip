@@ -40,7 +40,7 @@ struct DevState {
     bool ready = false, failed = false;
     hipModule_t mod = nullptr;
     hipFunction_t fn[2][2][2][2] = {};  // [a64 / a16][bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
-    hipFunction_t fn8[2][2] = {};       // a8: [e4m3 / e5m2][non-causal / causal], N % 256 == 0
+    hipFunction_t fn8[2][2][2] = {};    // a8: [e4m3 / e5m2][non-causal / causal][N % 256 == 0 / ragged]
     hipFunction_t fnd[2][2][2] = {};    // a64d (head size 64): [bf16 / f16][non-causal / causal][N % 256 == 0 / ragged]
     int cus = 0;
 };
@@ -82,12 +82,13 @@ DevState *dev_state() {
                     if (e != hipSuccess) d.fn[m][t][c][r] = nullptr;  // a kernel the generator did not emit: reported at launch
                 }
     for (int t = 0; t < 2; ++t)
-        for (int c = 0; c < 2; ++c) {
-            char nm[64];
-            snprintf(nm, sizeof(nm), "fa2_fwd_a8_%s_%s", t ? "e5m2" : "e4m3", c ? "c" : "n");
-            e = hipModuleGetFunction(&d.fn8[t][c], d.mod, nm);
-            if (e != hipSuccess) d.fn8[t][c] = nullptr;
-        }
+        for (int c = 0; c < 2; ++c)
+            for (int r = 0; r < 2; ++r) {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "fa2_fwd_a8_%s_%s%s", t ? "e5m2" : "e4m3", c ? "c" : "n", r ? "r" : "");
+                e = hipModuleGetFunction(&d.fn8[t][c][r], d.mod, nm);
+                if (e != hipSuccess) d.fn8[t][c][r] = nullptr;
+            }
     for (int t = 0; t < 2; ++t)
         for (int c = 0; c < 2; ++c)
             for (int r = 0; r < 2; ++r) {
@@ -127,10 +128,10 @@ int launch(const Fa2Problem &p, int shape16);
 }
 
 // fp8: one byte per element, rows of 128 bytes; otherwise the conditions of the 16-bit kernels (16-byte aligned rows and bases,
-// N * row stride below 2 GiB); N a multiple of 256 (every other fp8 shape: fa2_mfma8x.hip)
+// N * row stride below 2 GiB); N >= 256 (a multiple of 256: the plain kernels, else the ragged ones; every other fp8 shape: fa2_mfma8x.hip)
 bool fa2_a8_supports(const Fa2Problem &p) {
     if (p.dtype != FA2_DTYPE_F8E4M3 && p.dtype != FA2_DTYPE_F8E5M2) return false;
-    if (p.d != 128 || p.N < 256 || (p.N & 255)) return false;
+    if (p.d != 128 || p.N < 256) return false;
     if (p.qs[3] != 1 || p.ks[3] != 1 || p.vs[3] != 1 || p.os[3] != 1) return false;
     if (!(p.scale > 0.0f) || !isfinite(p.scale)) return false;
     const int64_t rows[4] = {p.qs[2], p.ks[2], p.vs[2], p.os[2]};
@@ -160,7 +161,7 @@ bool fa2_a64d_supports(const Fa2Problem &p) {
         if (ptrs[k] & 15) return false;
     if (((p.qs[0] | p.qs[1] | p.ks[0] | p.ks[1] | p.vs[0] | p.vs[1] | p.os[0] | p.os[1]) & 7) != 0) return false;
     if ((uintptr_t)p.L & 1) return false;
-    const int64_t nq = p.N / 256, jobs = (int64_t)p.B * p.H * nq;
+    const int64_t nq = (p.N + 255) / 256, jobs = (int64_t)p.B * p.H * nq;
     if (jobs >= (1 << 22) || p.H >= (1 << 22) || p.ls[1] < p.N) return false;
     return true;
 }
@@ -183,7 +184,7 @@ int launch(const Fa2Problem &p, int shape16) {
         }
     } else if (f8) {
         if (!fa2_a8_supports(p)) {
-            fa2_set_error("a8 kernel: needs fp8 (e4m3fn / e5m2), d = 128, N a multiple of 256, unit d-stride, 16-byte aligned rows");
+            fa2_set_error("a8 kernel: needs fp8 (e4m3fn / e5m2), d = 128, N >= 256, unit d-stride, 16-byte aligned rows");
             return FA2_ERR_UNSUPPORTED;
         }
     } else if (!fa2_a64_supports(p)) {
@@ -193,7 +194,7 @@ int launch(const Fa2Problem &p, int shape16) {
     }
     DevState *d = dev_state();
     if (!d) return FA2_ERR_LAUNCH;
-    hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0][p.causal ? 1 : 0]
+    hipFunction_t fn = f8 ? d->fn8[p.dtype == FA2_DTYPE_F8E5M2 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0]
                      : d64 ? d->fnd[p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0]
                            : d->fn[shape16][p.dtype == FA2_DTYPE_F16 ? 1 : 0][p.causal ? 1 : 0][(p.N & 255) ? 1 : 0];
     if (!fn) {

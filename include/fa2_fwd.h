@@ -70,7 +70,7 @@ extern "C" {
                            /* weight); finite inputs are unaffected.                                                          */
 #define FA2_VARIANT_A16 25 /* the A64 structure on the other matrix shape, v_mfma_f32_16x16x32 (the chip holds a higher clock on it):  */
                            /* same shapes, same job stream; a 64-key step is 136 MFMAs of 16 cycles instead of 72 of 32.          */
-#define FA2_VARIANT_A8 26  /* OCP fp8 (e4m3fn, e5m2), d = 128, N a multiple of 256 (causal or not): the A64 structure on the double-rate */
+#define FA2_VARIANT_A8 26  /* OCP fp8 (e4m3fn, e5m2), d = 128, N >= 256 (causal or not): the A64 structure on the double-rate            */
                            /* v_mfma_f32_32x32x64_f8f6f4 (generated assembly, asm/fa2_a8_gen.py), P.V on its block-scaled form: the  */
                            /* running maximum is an integer and rides in P's scale operand, O is never rescaled; BASELINE configs[4]  */
 #define FA2_VARIANT_A64D 27 /* f16/bf16, HEAD SIZE 64, N a multiple of 256: the A64 kernel at d = 64 (generated assembly,            */

@@ -21,17 +21,18 @@ ORACLE_DT = {"e4m3": "float8_e4m3fn", "e5m2": "float8_e5m2"}
 _PROGS = {}
 
 
-def prog(dtype, scaled=True, causal=False):
-    if (dtype, scaled, causal) not in _PROGS:
-        g = Gen(dtype, causal, scaled=scaled)
-        _PROGS[dtype, scaled, causal] = (g, g.build())
-    return _PROGS[dtype, scaled, causal]
+def prog(dtype, scaled=True, causal=False, ragged=False):
+    if (dtype, scaled, causal, ragged) not in _PROGS:
+        g = Gen(dtype, causal, scaled=scaled, ragged=ragged)
+        _PROGS[dtype, scaled, causal, ragged] = (g, g.build())
+    return _PROGS[dtype, scaled, causal, ragged]
 
 
 @pytest.mark.parametrize("dtype", ["e4m3", "e5m2"])
 @pytest.mark.parametrize("causal", [False, True])
-def test_generated_stream_has_no_wait_state_violation(dtype, causal):
-    assert check(prog(dtype, causal=causal)[1], verbose=False) == []
+@pytest.mark.parametrize("ragged", [False, True])
+def test_generated_stream_has_no_wait_state_violation(dtype, causal, ragged):
+    assert check(prog(dtype, causal=causal, ragged=ragged)[1], verbose=False) == []
 
 
 def test_generated_module_assembles_for_gfx950(tmp_path):
@@ -49,7 +50,7 @@ def _run(oracle, dtype, B, H, N, seed=0, spread=0.5, spike=False, scaled=True, c
     Q, K, V = (rng.standard_normal((B, H, N, 128)).astype(np.float32) * spread for _ in range(3))
     if spike:   # one row's maximum jumps far beyond the deferral threshold in the last tile (spike = the factor on the row's own q)
         K[:, :, N - 40] = float(spike) * Q[:, :, 5]
-    O, L, _ = harness.run(prog(dtype, scaled, causal)[1], Q, K, V, dtype=dtype, causal=causal, **kw)
+    O, L, _ = harness.run(prog(dtype, scaled, causal, bool(N % 256))[1], Q, K, V, dtype=dtype, causal=causal, **kw)
     rd = lambda x: harness.from_dt(harness.to_dt(x, dtype), dtype)
     kw.pop("pairs", None)
     O_ref, L_ref = oracle.forward_deferred(rd(Q), rd(K), rd(V), ORACLE_DT[dtype], causal=causal, G=32, B_c=64,
@@ -85,6 +86,15 @@ def test_emulated_causal_kernel(oracle):
     _run(oracle, "e4m3", 1, 1, 256, causal=True)
     _run(oracle, "e4m3", 1, 3, 768, causal=True, nwg=1, seed=3, spread=0.7)
     _run(oracle, "e5m2", 1, 1, 1024, causal=True, seed=2, spread=1.0, pairs=True)
+
+
+def test_emulated_ragged_kernels(oracle):
+    """N not a multiple of 256: range-checked descriptors (rows of 128 bytes), the key tail of the job's last four tiles masked on the
+    fp32 scores, wholly unreal tiles through +inf as running maximum; byte stores of L past N dropped"""
+    _run(oracle, "e4m3", 1, 1, 300)
+    _run(oracle, "e4m3", 1, 1, 257, seed=1)
+    _run(oracle, "e5m2", 1, 3, 513, nwg=1, seed=2)
+    _run(oracle, "e4m3", 1, 2, 700, causal=True, seed=3, spread=0.7)
 
 
 def test_emulated_guard_path_rebases_the_accumulators(oracle):

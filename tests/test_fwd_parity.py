@@ -439,9 +439,24 @@ def test_generated_fp8_kernel_a8(oracle, dtype):
     O, L = hip_forward(Q, K, V, variant="a8")
     O2, L2 = hip_forward(Q.contiguous(), K.contiguous(), V.contiguous(), variant="a8")
     assert torch.equal(u8(O), u8(O2)) and torch.equal(u8(L), u8(L2))
-    x = torch.zeros(1, 2, 320, 128).to(dtype)
+    for shape, seed, causal in (((1, 2, 300, 128), 25, False), ((2, 3, 1000, 128), 26, False), ((1, 4, 2049, 128), 27, True), ((1, 24, 1333, 128), 28, True)):
+        Q, K, V = _rand(shape, dtype, seed=seed, spread=0.6)       # ragged N (range-checked rows, masked key tail): canaries behind O and L
+        N = shape[2]
+        arena_o = torch.full((shape[0], shape[1], N + 8, 128), 1.0, device=DEV).to(dtype)
+        arena_l = torch.full((shape[0], shape[1], N + 8, 1), 1.0, device=DEV).to(dtype)
+        Oa, La = arena_o[:, :, :N], arena_l[:, :, :N]
+        _lib.fa2_fwd(Q.to(DEV), K.to(DEV), V.to(DEV), Oa, La, fa.convert_triton_dtype(dtype), causal=causal, variant=_lib.VARIANT_A8)
+        torch.cuda.synchronize()
+        assert (arena_o[:, :, N:].float() == 1.0).all() and (arena_l[:, :, N:].float() == 1.0).all(), shape
+        O8, L8 = hip_forward(Q, K, V, causal=causal, variant="mfma8x")
+        _fp8_close(Oa.cpu(), La.cpu(), O8, L8, V, step, same_o=0.5, same_l=0.9, l_abs=1.5 * step)
+        if shape[0] * shape[1] <= 6:
+            O_ref, L_ref = oracle.forward_deferred(f(Q), f(K), f(V), ORACLE_NAME[dtype], causal=causal, G=32, B_c=64, thr=FP8_THR[dtype],
+                                                   sum_rounded=True, ceil_m=True)
+            _fp8_close(Oa.cpu(), La.cpu(), torch.from_numpy(O_ref), torch.from_numpy(L_ref), V, step, same_o=0.98)
+    x = torch.zeros(1, 2, 192, 128).to(dtype)
     with pytest.raises(TypeError):
-        hip_forward(x, x, x, variant="a8")                 # N not a multiple of 256
+        hip_forward(x, x, x, variant="a8")                 # N below 256
     for shape, seed, spread in (((1, 2, 256, 128), 15, 0.5), ((2, 3, 768, 128), 16, 0.7), ((1, 24, 1024, 128), 17, 1.0), ((1, 4, 2048, 128), 18, 1.0),
                                 ((1, 8, 4096, 128), 19, 1.0), ((1, 8, 4352, 128), 20, 0.7)):      # (16 / 17 query blocks: the last with, the first without the downward walk)
         Q, K, V = _rand(shape, dtype, seed=seed, spread=spread)      # the causal form (light jobs walk downwards from N = 512 on)
