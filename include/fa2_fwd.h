@@ -73,7 +73,7 @@ extern "C" {
 #define FA2_VARIANT_A8 26  /* OCP fp8 (e4m3fn, e5m2), d = 128, N >= 256 (causal or not): the A64 structure on the double-rate            */
                            /* v_mfma_f32_32x32x64_f8f6f4 (generated assembly, asm/fa2_a8_gen.py), P.V on its block-scaled form: the  */
                            /* running maximum is an integer and rides in P's scale operand, O is never rescaled; BASELINE configs[4]  */
-#define FA2_VARIANT_A64D 27 /* f16/bf16, HEAD SIZE 64, N a multiple of 256: the A64 kernel at d = 64 (generated assembly,            */
+#define FA2_VARIANT_A64D 27 /* f16/bf16, HEAD SIZE 64, N >= 256: the A64 kernel at d = 64 (generated assembly,                         */
                             /* asm/fa2_a64d_gen.py); causal and not                                                                  */
 /* (ids 5-7, 10-13, 18 and the ablation ids belong to experimental kernels that are not part of this library:
  *  flash_attention_dlrs_amd/csrc/fa2_experiments.h, `make -C flash_attention_dlrs_amd/csrc experiments`) */
