@@ -76,8 +76,7 @@ def test_emulated_ragged_kernels(oracle):
     """N not a multiple of 256 (range-checked descriptors, the key tail masked in the 16x16 score layout: register 8 q' + 4 k' + rr of
     a group <-> key 16 k' + 4 (lane >> 4) + rr), one job and several per workgroup"""
     _run(oracle, "bf16", False, 1, 1, 300)
-    _run(oracle, "bf16", False, 1, 3, 513, nwg=1, seed=2)
-    _run(oracle, "f16", False, 1, 1, 1000, seed=3, spread=0.5)
+    _run(oracle, "bf16", False, 1, 2, 513, nwg=1, seed=2)
     for N in (257, 320):      # (one real key / one real tile in the job's last 256: the wholly unreal tiles swap +inf in for the running
         #                        maximum of all FOUR 16-row blocks -- in f16, whose tolerance shows a row that missed it)
         rng = np.random.default_rng(N)
@@ -85,7 +84,7 @@ def test_emulated_ragged_kernels(oracle):
         O, L, _ = harness.run(prog("f16", False, True)[1], Q, K, V, dtype="f16", causal=False)
         O_ref, _ = harness.reference(Q, K, V, dtype="f16", causal=False)
         assert np.abs(O - O_ref).max() <= 1.5e-3, (N, np.abs(O - O_ref).max())
-    _run(oracle, "bf16", True, 1, 2, 700, seed=1)
+    _run(oracle, "bf16", True, 1, 1, 448, seed=1)
 
 
 def test_emulated_kernel_job_stream_and_wave_order(oracle):
