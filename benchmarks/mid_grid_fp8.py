@@ -29,14 +29,14 @@ def t(fn, it=20):
 
 
 for causal in ((False,) if os.environ.get("MID_GRID_NONCAUSAL") else (True,) if os.environ.get("MID_GRID_CAUSAL") else (False, True)):
-    for N in (512, 1024, 2048, 4096, 8192):
+    for N in [int(x) for x in os.environ.get("MID_GRID_N", "512,1024,2048,4096,8192").split(",")]:
         for BH in (8, 16, 24, 32, 48, 64, 128):
             wg256 = BH * ((N + 255) // 256)
             if wg256 < 64 or wg256 > 2100:
                 continue
             Q, K, V = ((torch.randn(1, BH, N, 128, device=dev) * float(os.environ.get("MID_GRID_SPREAD", "1.0"))).to(torch.float8_e4m3fn) for _ in range(3))
             r = {"causal": causal, "N": N, "BH": BH, "wg256": wg256}
-            cands = ("mfma8x", "mfma8x_w4") + (() if N % 256 else ("a8",))     # (mfma8u: experiments library only)
+            cands = ("mfma8x", "mfma8x_w4") + (() if N < 256 else ("a8",))     # (mfma8u: experiments library only)
             for v in ("auto",) + cands:
                 r[v] = round(t(lambda: flash_attention_forward(Q, K, V, dev, causal=causal, variant=v)), 1)
             r["best"] = min(cands, key=lambda k: r[k])
