@@ -160,6 +160,7 @@ class Gen:
         # for all four waves instead of on both for a shrinking set of waves -- see build()
         assert split, "the a16 kernels use the split row map only"
         self.split = bool(split) and causal
+        assert self.split or not causal, "a16: the causal kernels use the split row map (the contiguous map's lean bodies know two maxima per wave, not four)"
         self.cls = None        # split seam bodies: "low" (waves 0, 1) / "high" (waves 2, 3) while their code is generated
         self.ragged = ragged   # N is not a multiple of 256: range-checked descriptors, every offset in the VGPR operand, masked key tail
         assert not (ragged and stamps), "the ragged kernels use the stamps' temporaries as address registers"
