@@ -81,16 +81,17 @@ def a64_cases():
     return out
 
 
+@pytest.mark.parametrize("variant", ["a64", "a16"])
 @pytest.mark.parametrize("B,H,N,dtype,causal,scale,layout", a64_cases(), ids=lambda v: str(v).replace("torch.", ""))
-def test_random_a64_problem(B, H, N, dtype, causal, scale, layout):
-    """the generated assembly kernel over random (B, H, N) -- one job to many per workgroup, N ragged or not -- scales and
+def test_random_a64_problem(B, H, N, dtype, causal, scale, layout, variant):
+    """the generated assembly kernels (both matrix shapes) over random (B, H, N) -- one job to many per workgroup, N ragged or not -- scales and
     storage layouts ((B, N, H, d) permuted views, rows padded to 136 elements), against fp64 attention on the device"""
     g = torch.Generator().manual_seed(N * 7919 + B * 31 + H)
     mk = {"contiguous": lambda: (torch.randn(B, H, N, 128, generator=g) * 0.7).to(dtype).to(DEV),
           "bnhd": lambda: (torch.randn(B, N, H, 128, generator=g) * 0.7).to(dtype).to(DEV).transpose(1, 2),
           "padded_rows": lambda: (torch.randn(B, H, N, 136, generator=g) * 0.7).to(dtype).to(DEV)[..., :128]}[layout]
     Q, K, V = mk(), mk(), mk()
-    O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal, scale=scale, variant="a64")
+    O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal, scale=scale, variant=variant)
     q, k, v = (t.double() for t in (Q, K, V))
     S = (q @ k.transpose(-1, -2)) * scale
     if causal:
