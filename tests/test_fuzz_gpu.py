@@ -137,3 +137,23 @@ def test_random_a8_problem(B, H, N, dtype, causal, scale, layout, spread):
     assert rel.median().item() <= step / 2 and rel.kthvalue(int(0.99 * rel.numel())).values.item() <= 3 * step, \
         (rel.median().item(), rel.kthvalue(int(0.99 * rel.numel())).values.item())
     assert ((L.double() - L_t).abs() <= step * L_t.abs() + 1.5 * step).all()
+
+
+@pytest.mark.parametrize("B,H,N,dtype,causal,scale,layout", a64_cases()[:16], ids=lambda v: str(v).replace("torch.", ""))
+def test_random_a64d_problem(B, H, N, dtype, causal, scale, layout):
+    """the generated kernel at head size 64 over the same random problems (ragged N or not, scales, storage layouts)"""
+    g = torch.Generator().manual_seed(N * 7919 + B * 31 + H + 64)
+    mk = {"contiguous": lambda: (torch.randn(B, H, N, 64, generator=g) * 0.7).to(dtype).to(DEV),
+          "bnhd": lambda: (torch.randn(B, N, H, 64, generator=g) * 0.7).to(dtype).to(DEV).transpose(1, 2),
+          "padded_rows": lambda: (torch.randn(B, H, N, 72, generator=g) * 0.7).to(dtype).to(DEV)[..., :64]}[layout]
+    Q, K, V = mk(), mk(), mk()
+    O, L = fa.flash_attention_forward(Q, K, V, DEV, causal=causal, scale=scale, variant="a64d")
+    q, k, v = (t.double() for t in (Q, K, V))
+    S = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        S = S.masked_fill(~torch.ones(N, N, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+    O_t = torch.softmax(S, dim=-1) @ v
+    L_t = torch.logsumexp(S, dim=-1, keepdim=True) * math.log2(math.e)
+    assert (O.double() - O_t).abs().max().item() <= REL[dtype] * max(1.0, O_t.abs().max().item())
+    lu = 2.0 ** (math.floor(math.log2(max(L_t.abs().max().item(), 1e-9))) - (7 if dtype == torch.bfloat16 else 10))
+    assert (L.double() - L_t).abs().max().item() <= 1.01 * lu
