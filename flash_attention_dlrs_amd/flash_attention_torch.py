@@ -66,7 +66,8 @@ def forward_head_size(dtype, B, H, N, d):
         multiple of 8 on every shape measured;
       * f16 / bf16, 64 < d < 128 a multiple of 8: the d-predicated kernel as it is on small grids (29 vs 45 us at B2 H8 N1024), padded
         to 128 from 128 Ki rows on (B4 H32 N4096 d = 96: 1.08 -> 0.90 ms);
-      * fp32, d not a multiple of 4: the next multiple of 4 (the predicated fp32 MFMA kernel).
+      * fp32, d not a multiple of 4: the next multiple of 4 (the predicated fp32 MFMA kernel);
+      * fp8, d < 128: 128 (fp8 runs on the matrix cores at that head size only).
     Zero-padding is exact: the extra products are zeros, the extra columns of O are sliced away (torch.py:81-82)."""
     if dtype in (torch.float16, torch.bfloat16) and d <= 128:
         if d % 8:
@@ -75,6 +76,8 @@ def forward_head_size(dtype, B, H, N, d):
             return 128
     if dtype == torch.float32 and d <= 128 and d % 4:
         return (d + 3) // 4 * 4
+    if dtype in (torch.float8_e4m3fn, torch.float8_e5m2) and d < 128:
+        return 128       # (the fp8 matrix kernels exist at d = 128 only; any other head size would run on the VALU kernel)
     return d
 
 
