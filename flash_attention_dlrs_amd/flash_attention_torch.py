@@ -57,7 +57,7 @@ def pad_last_dim(t, d_proper):
     return torch.nn.functional.pad(t, (0, d_proper - d), mode="constant", value=0.0)
 
 
-def forward_head_size(dtype, B, H, N, d):
+def forward_head_size(dtype, B, H, N, d, causal=False):
     """Head size the forward kernels are RUN at.  The kernels take any d (the reference pads every d that is not a power of two,
     torch.py:38-47), but only some on the matrix cores: f16 / bf16 multiples of 8 and fp32 multiples of 4 up to 128.  Everything
     else would run on the VALU kernel, 60-90 times slower than a zero-padded launch (profiles/r03/pad_vs_predicated.jsonl: bf16
@@ -65,7 +65,8 @@ def forward_head_size(dtype, B, H, N, d):
       * f16 / bf16, d not a multiple of 8: pad to 64 (d < 64) or 128 -- the pipelined kernels; as fast as or faster than the next
         multiple of 8 on every shape measured;
       * f16 / bf16, 64 < d < 128 a multiple of 8: the d-predicated kernel as it is on small grids (29 vs 45 us at B2 H8 N1024), padded
-        to 128 from 128 Ki rows on (B4 H32 N4096 d = 96: 1.08 -> 0.90 ms);
+        to 128 from 128 Ki rows on (B4 H32 N4096 d = 96: 1.08 -> 0.90 ms); d < 64 a multiple of 8: as it is, except causal problems of
+        256 Ki rows and more, which go to the generated d = 64 kernel (+13 .. 26 %, profiles/r03/pad_small_d.jsonl);
       * fp32, d not a multiple of 4: the next multiple of 4 (the predicated fp32 MFMA kernel);
       * fp8, d < 128: 128 (fp8 runs on the matrix cores at that head size only).
     Zero-padding is exact: the extra products are zeros, the extra columns of O are sliced away (torch.py:81-82)."""
@@ -74,6 +75,9 @@ def forward_head_size(dtype, B, H, N, d):
             return 64 if d < 64 else 128
         if 64 < d < 128 and B * H * N >= 131072:
             return 128
+        if d < 64 and causal and B * H * N >= 262144:
+            return 64      # (multiples of 8 below 64, causal, large: the generated d = 64 kernel, 0.34 vs 0.43 ms at B4 H32 N4096 d = 16 .. 48;
+            #                non-causal the two are level, and below that size the pad copies cost more than they buy)
     if dtype == torch.float32 and d <= 128 and d % 4:
         return (d + 3) // 4 * 4
     if dtype in (torch.float8_e4m3fn, torch.float8_e5m2) and d < 128:
@@ -103,7 +107,7 @@ def _forward_impl(ctx, Q, K, V, causal, scale):
     # power of two and pads what it was handed (_backward_impl).
     d_proper = max(next_power_of_2(d), MIN_TENSOR_SIZE)
     padded = d_proper != d
-    d_run = forward_head_size(Q.dtype, B, H, N, d)
+    d_run = forward_head_size(Q.dtype, B, H, N, d, causal)
 
     # O inherits Q's strides, L is (B, H, N, 1) in the input dtype (reference torch.py:50-51)
     L = torch.empty(B, H, N, 1, dtype=Q.dtype, device=Q.device)

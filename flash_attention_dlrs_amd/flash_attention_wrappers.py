@@ -25,7 +25,7 @@ def flash_attention_forward(Q, K, V, dev, *, causal=False, scale=1.0, variant="a
     # (forward_head_size).  A forced variant gets the tensors as they are.
     d_out = d
     if variant == "auto":
-        d = forward_head_size(Q.dtype, B, H, N, d)
+        d = forward_head_size(Q.dtype, B, H, N, d, causal)
         if d != d_out:
             Q, K, V = (pad_last_dim(t, d) for t in (Q, K, V))
 

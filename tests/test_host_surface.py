@@ -127,6 +127,7 @@ def test_forward_head_size_keeps_odd_head_sizes_on_the_matrix_cores():
         assert [f(dt, 4, 32, 4096, d) for d in (100, 36, 20, 1, 63, 65, 127)] == [128, 64, 64, 64, 64, 128, 128]
         assert [f(dt, 2, 8, 1024, d) for d in (8, 24, 40, 48, 64, 80, 96, 120, 128, 136, 256)] == [8, 24, 40, 48, 64, 80, 96, 120, 128, 136, 256]
         assert [f(dt, 4, 32, 4096, d) for d in (40, 64, 80, 96, 120, 128)] == [40, 64, 128, 128, 128, 128]     # large grids: the pipelined kernels
+        assert [f(dt, 4, 32, 4096, d, True) for d in (16, 40, 48, 64)] == [64, 64, 64, 64] and f(dt, 8, 16, 1024, 32, True) == 32    # (causal, large)
     assert [f(torch.float32, 1, 2, 70, d) for d in (37, 50, 30, 96, 40, 8, 130)] == [40, 52, 32, 96, 40, 8, 130]
     assert f(torch.float64, 1, 2, 70, 37) == 37
     for dt in (torch.float8_e5m2, torch.float8_e4m3fn):       # fp8 has matrix kernels at d = 128 only: anything below is padded to it
